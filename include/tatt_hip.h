@@ -1,0 +1,110 @@
+/* libtatt_hip.so — C ABI of the MI355X-native TATT super-resolution hot path.
+ *
+ * Drop-in boundary: the reference is pure Python on stock torch ops; it has no FFI of its
+ * own.  Each entry point below replaces the stock op(s) the reference reaches through torch.nn at the cited
+ * reference file:line (paths relative to the reference tree).  Conventions:
+ *   - every pointer is a DEVICE pointer to fp32 unless noted; the caller owns all memory, incl. workspaces;
+ *   - the library never allocates, frees or synchronises; all work is enqueued on `stream`;
+ *   - return 0 on success, non-zero otherwise (message via tatt_last_error(), thread-local);
+ *   - activations are NHWC ("rows x channels": row = (batch, y, x)); `ld*` = floats between rows;
+ *   - dropout sites take (seed_site, thresh, scale): keep iff (hash(seed_site, index) >> 8) >= thresh,
+ *     kept values are multiplied by scale = 1/(1-p); thresh == 0 disables dropout.
+ * tatt_amd/lib.py parses this header to build the ctypes signatures: keep one declaration per statement and
+ * use only the scalar types  int, long, float, uint32_t, size_t, hipStream_t  and (const) float* / void*.
+ */
+#ifndef TATT_HIP_H
+#define TATT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef void* hipStream_t;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* tatt_last_error(void);
+int tatt_version(void);
+
+/* ---- fp32 MFMA GEMM: every nn.Linear / 1x1 conv / attention projection / GRU input projection ----------
+ * C[m*ldc+n] = sum_k A[m*sam+k*sak] * B[n*sbn+k*sbk] (+bias[n]) (+C) (relu).  Replaces F.linear at
+ * model/tsrn.py:213, :1083 (1x1 conv), model/transformer_v2.py:476,:480,:819,:829 (MHA in/out proj, FFN),
+ * nn.GRU input projections (model/tsrn.py:1088, model/transformer_v2.py:218), stn_head.py:99-100. */
+size_t tatt_gemm_workspace(int M, int N, int splitk);
+int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int batch, long sAb, long sBb, long sCb, int accumulate, int relu, int splitk, float* workspace, hipStream_t stream);
+
+/* ---- NHWC implicit-GEMM convolution (stride 1, "same" zero padding), fwd / dgrad / wgrad -------------------
+ * Replaces nn.Conv2d at model/tsrn.py:598 (9x9 4->64), :868,:876 (SRB 3x3), :614, :1034 (64->256), :625
+ * (9x9 64->4) and model/stn_head.py:15.  Weights stay in the reference's OIHW layout; (w_sn,w_sci,w_base,
+ * w_stap) describe how (cout, cin, tap) is addressed: forward (Cin*T, T, 0, 1); dgrad (T, Cin_f*T, T-1, -1). */
+int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu, hipStream_t stream);
+size_t tatt_conv_wgrad_workspace(int Cin, int Cout, int KH, int KW, int splitk);
+int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long lddy, int splitk, float* workspace, int accumulate, hipStream_t stream);
+
+/* ---- BatchNorm2d/1d (model/tsrn.py:869,:877,:615; model/stn_head.py:19,:51) ------------------------------- */
+size_t tatt_bn_workspace(int C);
+int tatt_bn_stats(const float* x, long ldx, int R, int C, float eps, float momentum, float* stat, float* run_mean, float* run_var, float* workspace, hipStream_t stream);
+int tatt_bn_stat_from_running(const float* rm, const float* rv, int C, float eps, float* stat, hipStream_t stream);
+int tatt_bn_apply(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr, float* y, long ldy, int R, int C, int act, hipStream_t stream);
+int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const float* stat, const float* gamma, const float* beta, float* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int act, int train, int accumulate_params, int accumulate_dx, float* workspace, hipStream_t stream);
+
+/* ---- LayerNorm(64) with fused residual + dropout (model/transformer_v2.py:478-482, :827-831, :380) -------- */
+int tatt_ln_fwd(const float* x, const float* res, uint32_t seed_site, uint32_t thresh, float scale, const float* gamma, const float* beta, float* vout, float* y, int rows, float eps, hipStream_t stream);
+size_t tatt_ln_workspace(int rows);
+int tatt_ln_bwd(const float* v, const float* dy, float dyscale, const float* gamma, float* dv, int dv_accumulate, float* dres, uint32_t seed_site, uint32_t thresh, float scale, float* dgamma, float* dbeta, int accumulate_params, int rows, float eps, float* workspace, hipStream_t stream);
+
+/* ---- BiGRU(64 -> 2x32) recurrence of GruBlock (model/tsrn.py:1080,:1088), persistent half-wave per sequence - */
+int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* out, float* save, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride, hipStream_t stream);
+int tatt_gru32_bwd(const float* dout, const float* out, const float* save, const float* whh_f, const float* whh_b, float* dgi, float* dgh, float* hprev, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride, hipStream_t stream);
+
+/* ---- recurrent positional encoding GRU(1024 -> 2x512) gates (model/transformer_v2.py:177,:215-221) -------- */
+int tatt_rpe_gate_fwd(const float* gi, const float* gh, const float* bhh_f, const float* bhh_b, const float* hprev, float* hout, float* qp, int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t stream);
+int tatt_rpe_gate_bwd(const float* gi, const float* gh, const float* bhh_f, const float* bhh_b, const float* hprev, const float* dqp, float* carry, float* dgh, float* dgi_sum, int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t stream);
+int tatt_rpe_gather_x(const float* init_factor, float* x, hipStream_t stream);
+int tatt_rpe_scatter_dx(const float* dx, float* dinit, int accumulate, hipStream_t stream);
+
+/* ---- attention core, 4 heads x 16, 26 keys (nn.MultiheadAttention at model/transformer_v2.py:476,:819) ---- */
+int tatt_attn_fwd(const float* Q, const float* Kp, const float* Vp, float* ctx, float* pw, int B, int Lq, int nkeys, uint32_t seed_site, uint32_t thresh, float scale, hipStream_t stream);
+int tatt_attn_bwd(const float* Q, const float* Kp, const float* Vp, const float* dctx, float* dQ, float* dK, float* dV, int B, int Lq, int nkeys, uint32_t seed_site, uint32_t thresh, float scale, int accumulate_kv, hipStream_t stream);
+int tatt_attn_avg(const float* pw, float* out, int B, int Lq, hipStream_t stream);
+
+/* ---- element-wise / layout (model/tsrn.py:599 PReLU, :1042-1043 PixelShuffle+mish, :683 sigmoid, :208, :212;
+ *      model/stn_head.py:36-44 MaxPool2d; model/transformer_v2.py:39-42 PE+dropout, :480 FFN dropout) -------- */
+int tatt_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, hipStream_t stream);
+int tatt_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, hipStream_t stream);
+int tatt_axpby(const float* a, float alpha, const float* b, float beta, float* out, long n, int accumulate, hipStream_t stream);
+int tatt_prelu_fwd(const float* x, const float* slope, float* y, long n, hipStream_t stream);
+int tatt_prelu_bwd(const float* x, const float* slope, const float* dy, float* dx, float* dslope, int accumulate, long n, float* workspace, hipStream_t stream);
+size_t tatt_colsum_workspace(int C);
+int tatt_colsum(const float* x, long ld, int R, int C, float* out, int accumulate, float* workspace, hipStream_t stream);
+int tatt_pixshuf_mish_fwd(const float* x, float* y, int B, int H, int W, int C, hipStream_t stream);
+int tatt_pixshuf_mish_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, hipStream_t stream);
+int tatt_sigmoid_to_nchw(const float* pre, float* sr, int B, int C, int HW, hipStream_t stream);
+int tatt_sigmoid_bwd_to_nhwc(const float* sr, const float* dsr, float* dpre, int B, int C, int HW, hipStream_t stream);
+int tatt_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int kh, int kw, hipStream_t stream);
+int tatt_maxpool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int kh, int kw, hipStream_t stream);
+int tatt_tp_rows(const float* tp, long sB, long sK, long sL, float* out, int B, int K, int L, hipStream_t stream);
+int tatt_pe_dropout(const float* pe, float* pos, int B, int L, uint32_t seed_site, uint32_t thresh, float scale, hipStream_t stream);
+int tatt_dropout_mul(const float* x, float* y, long n, uint32_t seed_site, uint32_t thresh, float scale, hipStream_t stream);
+int tatt_relu_drop_bwd(const float* h, const float* dh, float* out, long n, uint32_t seed_site, uint32_t thresh, float scale, hipStream_t stream);
+
+/* ---- TPS rectification = grid build + bilinear gather (model/tps_spatial_transformer.py:97-112, :10-11) and
+ *      the TSC rotation (interfaces/super_resolution_eng.py:50-82) ----------------------------------------- */
+int tatt_tps_sample_fwd(const float* x, const float* ctrl, const float* T, float* y, float* src_out, int B, int C, int H, int W, hipStream_t stream);
+int tatt_tps_sample_bwd(const float* x, const float* ctrl, const float* T, const float* dy, float* dctrl, int B, int C, int H, int W, int accumulate, hipStream_t stream);
+int tatt_rotate_fwd(const float* x, const float* arc, float* y, int B, int C, int H, int W, hipStream_t stream);
+int tatt_rotate_bwd(const float* arc, const float* dy, float* dx, int B, int C, int H, int W, hipStream_t stream);
+
+/* ---- ImageLoss = MSE + gradient-prior L1 (loss/image_loss.py:19-32, :40-56), NCHW ------------------------- */
+int tatt_image_loss_fwd(const float* sr, const float* hr, float* per, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);
+int tatt_image_loss_bwd(const float* sr, const float* hr, const float* dper, float uniform, float* dsr, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);
+
+/* ---- clip_grad_norm_ + Adam over a flat parameter buffer (interfaces/super_resolution_eng.py:277-279) ------ */
+int tatt_clip_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float max_norm, float* state, float* workspace, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,76 @@
+// Shared helpers for the tatt_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define TATT_OK 0
+#define TATT_ERR_ARG 1
+#define TATT_ERR_LAUNCH 2
+
+void tatt_set_error(const char* fmt, ...);
+
+#define TATT_CHECK_ARG(cond, ...)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      tatt_set_error(__VA_ARGS__);                \
+      return TATT_ERR_ARG;                        \
+    }                                             \
+  } while (0)
+
+#define TATT_LAUNCH_CHECK(name)                                              \
+  do {                                                                       \
+    hipError_t e_ = hipGetLastError();                                       \
+    if (e_ != hipSuccess) {                                                  \
+      tatt_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));  \
+      return TATT_ERR_LAUNCH;                                                \
+    }                                                                        \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- counter-based dropout (bit-identical to oracle/tatt_ref.py:hash_u32) -------------
+__device__ __forceinline__ uint32_t tatt_hash_u32(uint32_t seed_site, uint32_t idx) {
+  uint32_t x = idx * 0x9E3779B1u + seed_site;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+// host+device: fold (seed, site) like the oracle: (seed*0x85EBCA77 + site*0xC2B2AE3D) mod 2^32
+static inline __host__ __device__ uint32_t tatt_seed_site(uint32_t seed, uint32_t site) {
+  return seed * 0x85EBCA77u + site * 0xC2B2AE3Du;
+}
+// returns the multiplicative mask (0 or 1/(1-p)); thresh = (int)(p * 2^24); thresh==0 -> 1
+__device__ __forceinline__ float tatt_drop_mask(uint32_t seed_site, uint32_t idx, uint32_t thresh, float scale) {
+  if (thresh == 0) return 1.0f;
+  return ((tatt_hash_u32(seed_site, idx) >> 8) >= thresh) ? scale : 0.0f;
+}
+
+struct DropCfg {       // passed by value to kernels
+  uint32_t seed_site;  // tatt_seed_site(seed, site)
+  uint32_t thresh;     // 0 = dropout off
+  float scale;         // 1/(1-p)
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float mishf_(float x) { return x * tanhf(softplusf_(x)); }
+__device__ __forceinline__ float mish_gradf_(float x) {
+  float sp = softplusf_(x);
+  float t = tanhf(sp);
+  float s = 1.0f / (1.0f + expf(-x));
+  return t + x * (1.0f - t * t) * s;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,323 @@
+// HBM-bound element-wise / layout / small-reduction kernels of the SR path.
+#include "common.h"
+
+namespace {
+
+#define GRID1D(n) dim3(cdiv((n), 256)), dim3(256)
+
+__global__ void nchw_to_nhwc_k(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C * HW) return;
+  int c = (int)(i % C);
+  long p = i / C;  // b*HW + hw
+  long b = p / HW, hw = p - b * HW;
+  y[i] = x[(b * C + c) * HW + hw];
+}
+__global__ void nhwc_to_nchw_k(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C * HW) return;
+  long hw = i % HW;
+  long bc = i / HW;
+  long b = bc / C, c = bc - b * C;
+  y[i] = x[(b * HW + hw) * C + c];
+}
+
+// out = alpha*a + beta*b (b optional) (+ out if accumulate)
+__global__ void axpby_k(const float* __restrict__ a, float alpha, const float* __restrict__ b, float beta, float* __restrict__ out,
+                        long n, int accumulate) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = alpha * a[i];
+  if (b) v += beta * b[i];
+  if (accumulate) v += out[i];
+  out[i] = v;
+}
+
+__global__ void prelu_fwd_k(const float* __restrict__ x, const float* __restrict__ slope, float* __restrict__ y, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i];
+  y[i] = v > 0.f ? v : v * slope[0];
+}
+// dx = dy * (x>0 ? 1 : slope) ; partial[blk] = sum dy*x over x<=0
+__global__ __launch_bounds__(256) void prelu_bwd_k(const float* __restrict__ x, const float* __restrict__ slope,
+                                                   const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ partial,
+                                                   long n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const float a = slope[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = x[i], g = dy[i];
+    dx[i] = v > 0.f ? g : g * a;
+    if (!(v > 0.f)) s += g * v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sum_partials_k(const float* __restrict__ partial, int n, float scale, float* __restrict__ out, int accumulate) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += partial[i];
+  s *= scale;
+  out[0] = accumulate ? out[0] + s : s;
+}
+
+// column sums of [R,C] (ld) : stage 1 partial[blk][C]
+__global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict__ x, long ld, int R, int C, int rows_per_blk,
+                                                        float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int CT = C < 256 ? C : 256, RL = 256 / CT;
+  const int tid = threadIdx.x, cl = tid % CT, rl = tid / CT;
+  const int rb = blockIdx.x * rows_per_blk, re = min(R, rb + rows_per_blk);
+  for (int c = cl; c < C; c += CT) {
+    float s = 0.f;
+    if (rl < RL)
+      for (int r = rb + rl; r < re; r += RL) s += x[(long)r * ld + c];
+    red[tid] = (rl < RL) ? s : 0.f;
+    __syncthreads();
+    if (rl == 0) {
+      float t = 0.f;
+      for (int j = 0; j < RL; ++j) t += red[j * CT + cl];
+      partial[(long)blockIdx.x * C + c] = t;
+    }
+    __syncthreads();
+  }
+}
+__global__ void colsum_final_k(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(long)b * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// PixelShuffle(2)+mish: in NHWC [B,H,W,4C] (channel c*4 + i*2 + j) -> out NHWC [B,2H,2W,C]
+__global__ void pixshuf_mish_fwd_k(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * H * W * 4 * C) return;
+  int c = (int)(i % C);
+  long p = i / C;  // b, oy, ox
+  int ox = (int)(p % (2 * W));
+  long q = p / (2 * W);
+  int oy = (int)(q % (2 * H));
+  long b = q / (2 * H);
+  long src = ((b * H + (oy >> 1)) * W + (ox >> 1)) * 4 * C + c * 4 + (oy & 1) * 2 + (ox & 1);
+  y[i] = mishf_(x[src]);
+}
+// dx (layout of x) = dy(shuffled position) * mish'(x)
+__global__ void pixshuf_mish_bwd_k(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int B, int H,
+                                   int W, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * H * W * 4 * C) return;
+  int ch = (int)(i % (4 * C));
+  long p = i / (4 * C);
+  int xx = (int)(p % W);
+  long q = p / W;
+  int yy = (int)(q % H);
+  long b = q / H;
+  int c = ch >> 2, ii = (ch >> 1) & 1, jj = ch & 1;
+  long src = ((b * 2 * H + 2 * yy + ii) * 2 * W + 2 * xx + jj) * C + c;
+  dx[i] = dy[src] * mish_gradf_(x[i]);
+}
+
+// sr (NCHW) = sigmoid(pre NHWC [P,C])
+__global__ void sigmoid_to_nchw_k(const float* __restrict__ pre, float* __restrict__ sr, int B, int C, int HW) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C * HW) return;
+  long hw = i % HW;
+  long bc = i / HW;
+  long b = bc / C, c = bc - b * C;
+  sr[i] = sigmoidf_(pre[(b * HW + hw) * C + c]);
+}
+// dpre (NHWC) = dsr * sr * (1-sr)   (sr, dsr NCHW)
+__global__ void sigmoid_bwd_to_nhwc_k(const float* __restrict__ sr, const float* __restrict__ dsr, float* __restrict__ dpre, int B,
+                                      int C, int HW) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C * HW) return;
+  int c = (int)(i % C);
+  long p = i / C;
+  long b = p / HW, hw = p - b * HW;
+  long s = (b * C + c) * HW + hw;
+  float v = sr[s];
+  dpre[i] = dsr[s] * v * (1.f - v);
+}
+
+// NHWC max pool (kh x kw, stride = kernel)
+__global__ void maxpool_fwd_k(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int kh, int kw) {
+  const int OH = H / kh, OW = W / kw;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * OH * OW * C) return;
+  int c = (int)(i % C);
+  long p = i / C;
+  int ox = (int)(p % OW);
+  long q = p / OW;
+  int oy = (int)(q % OH);
+  long b = q / OH;
+  float m = -INFINITY;
+  for (int a = 0; a < kh; ++a)
+    for (int d = 0; d < kw; ++d) m = fmaxf(m, x[((b * H + oy * kh + a) * W + ox * kw + d) * C + c]);
+  y[i] = m;
+}
+// dx[window argmax (first in scan order)] = dy, other window elements 0
+__global__ void maxpool_bwd_k(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W,
+                              int C, int kh, int kw) {
+  const int OH = H / kh, OW = W / kw;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * OH * OW * C) return;
+  int c = (int)(i % C);
+  long p = i / C;
+  int ox = (int)(p % OW);
+  long q = p / OW;
+  int oy = (int)(q % OH);
+  long b = q / OH;
+  float m = -INFINITY;
+  int am = 0;
+  for (int a = 0; a < kh; ++a)
+    for (int d = 0; d < kw; ++d) {
+      float v = x[((b * H + oy * kh + a) * W + ox * kw + d) * C + c];
+      if (v > m) { m = v; am = a * kw + d; }
+    }
+  float g = dy[i];
+  for (int a = 0; a < kh; ++a)
+    for (int d = 0; d < kw; ++d) dx[((b * H + oy * kh + a) * W + ox * kw + d) * C + c] = (a * kw + d == am) ? g : 0.f;
+}
+
+// text prior [B,K,1,L] with arbitrary element strides -> rows [B*L, K]
+__global__ void tp_rows_k(const float* __restrict__ tp, long sB, long sK, long sL, float* __restrict__ out, int B, int K, int L) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * L * K) return;
+  int k = (int)(i % K);
+  long r = i / K;
+  long b = r / L, l = r - b * L;
+  out[i] = tp[b * sB + k * sK + l * sL];
+}
+
+// pos[(b*L+l)*64+c] = pe[l*64+c] * dropmask(index = same)
+__global__ void pe_dropout_k(const float* __restrict__ pe, float* __restrict__ pos, int B, int L, DropCfg dc) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * L * 64) return;
+  int c = (int)(i % 64);
+  int l = (int)((i / 64) % L);
+  pos[i] = pe[l * 64 + c] * tatt_drop_mask(dc.seed_site, (uint32_t)i, dc.thresh, dc.scale);
+}
+
+// y = x * dropmask(i)   (in place allowed)
+__global__ void dropout_mul_k(const float* __restrict__ x, float* __restrict__ y, long n, DropCfg dc) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  y[i] = x[i] * tatt_drop_mask(dc.seed_site, (uint32_t)i, dc.thresh, dc.scale);
+}
+// FFN hidden backward: dpre = dh * dropmask(i) * (h > 0)   (h = relu output before dropout)
+__global__ void relu_drop_bwd_k(const float* __restrict__ h, const float* __restrict__ dh, float* __restrict__ out, long n,
+                                DropCfg dc) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = h[i] > 0.f ? dh[i] * tatt_drop_mask(dc.seed_site, (uint32_t)i, dc.thresh, dc.scale) : 0.f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tatt_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(nchw_to_nhwc_k, GRID1D((long)B * C * HW), 0, st, x, y, B, C, HW);
+  TATT_LAUNCH_CHECK("nchw_to_nhwc");
+  return TATT_OK;
+}
+int tatt_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(nhwc_to_nchw_k, GRID1D((long)B * C * HW), 0, st, x, y, B, C, HW);
+  TATT_LAUNCH_CHECK("nhwc_to_nchw");
+  return TATT_OK;
+}
+int tatt_axpby(const float* a, float alpha, const float* b, float beta, float* out, long n, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(axpby_k, GRID1D(n), 0, st, a, alpha, b, beta, out, n, accumulate);
+  TATT_LAUNCH_CHECK("axpby");
+  return TATT_OK;
+}
+int tatt_prelu_fwd(const float* x, const float* slope, float* y, long n, hipStream_t st) {
+  hipLaunchKernelGGL(prelu_fwd_k, GRID1D(n), 0, st, x, slope, y, n);
+  TATT_LAUNCH_CHECK("prelu_fwd");
+  return TATT_OK;
+}
+// workspace: 1024 floats
+int tatt_prelu_bwd(const float* x, const float* slope, const float* dy, float* dx, float* dslope, int accumulate, long n,
+                   float* workspace, hipStream_t st) {
+  int nblk = cdiv(n, 256 * 8);
+  if (nblk > 1024) nblk = 1024;
+  hipLaunchKernelGGL(prelu_bwd_k, dim3(nblk), dim3(256), 0, st, x, slope, dy, dx, workspace, n);
+  TATT_LAUNCH_CHECK("prelu_bwd");
+  hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(64), 0, st, workspace, nblk, 1.0f, dslope, accumulate);
+  TATT_LAUNCH_CHECK("prelu_bwd_final");
+  return TATT_OK;
+}
+size_t tatt_colsum_workspace(int C) { return (size_t)256 * C; }
+int tatt_colsum(const float* x, long ld, int R, int C, float* out, int accumulate, float* workspace, hipStream_t st) {
+  TATT_CHECK_ARG(R > 0 && C > 0 && (C > 256 || 256 % C == 0 || true), "tatt_colsum: bad dims");
+  int rpb = R >= 64 * 256 ? cdiv(R, 256) : 64;
+  int nblk = cdiv(R, rpb);
+  // CT = min(C,256) must divide 256 for the row-lane split; otherwise fall back to one row lane
+  hipLaunchKernelGGL(colsum_partial_k, dim3(nblk), dim3(256), 0, st, x, ld, R, C, rpb, workspace);
+  TATT_LAUNCH_CHECK("colsum_partial");
+  hipLaunchKernelGGL(colsum_final_k, dim3(cdiv(C, 64)), dim3(64), 0, st, workspace, nblk, C, out, accumulate);
+  TATT_LAUNCH_CHECK("colsum_final");
+  return TATT_OK;
+}
+int tatt_pixshuf_mish_fwd(const float* x, float* y, int B, int H, int W, int C, hipStream_t st) {
+  hipLaunchKernelGGL(pixshuf_mish_fwd_k, GRID1D((long)B * H * W * 4 * C), 0, st, x, y, B, H, W, C);
+  TATT_LAUNCH_CHECK("pixshuf_mish_fwd");
+  return TATT_OK;
+}
+int tatt_pixshuf_mish_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, hipStream_t st) {
+  hipLaunchKernelGGL(pixshuf_mish_bwd_k, GRID1D((long)B * H * W * 4 * C), 0, st, x, dy, dx, B, H, W, C);
+  TATT_LAUNCH_CHECK("pixshuf_mish_bwd");
+  return TATT_OK;
+}
+int tatt_sigmoid_to_nchw(const float* pre, float* sr, int B, int C, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(sigmoid_to_nchw_k, GRID1D((long)B * C * HW), 0, st, pre, sr, B, C, HW);
+  TATT_LAUNCH_CHECK("sigmoid_to_nchw");
+  return TATT_OK;
+}
+int tatt_sigmoid_bwd_to_nhwc(const float* sr, const float* dsr, float* dpre, int B, int C, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(sigmoid_bwd_to_nhwc_k, GRID1D((long)B * C * HW), 0, st, sr, dsr, dpre, B, C, HW);
+  TATT_LAUNCH_CHECK("sigmoid_bwd_to_nhwc");
+  return TATT_OK;
+}
+int tatt_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int kh, int kw, hipStream_t st) {
+  TATT_CHECK_ARG(H % kh == 0 && W % kw == 0, "tatt_maxpool_fwd: H/W must divide");
+  hipLaunchKernelGGL(maxpool_fwd_k, GRID1D((long)B * (H / kh) * (W / kw) * C), 0, st, x, y, B, H, W, C, kh, kw);
+  TATT_LAUNCH_CHECK("maxpool_fwd");
+  return TATT_OK;
+}
+int tatt_maxpool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int kh, int kw, hipStream_t st) {
+  hipLaunchKernelGGL(maxpool_bwd_k, GRID1D((long)B * (H / kh) * (W / kw) * C), 0, st, x, dy, dx, B, H, W, C, kh, kw);
+  TATT_LAUNCH_CHECK("maxpool_bwd");
+  return TATT_OK;
+}
+int tatt_tp_rows(const float* tp, long sB, long sK, long sL, float* out, int B, int K, int L, hipStream_t st) {
+  hipLaunchKernelGGL(tp_rows_k, GRID1D((long)B * L * K), 0, st, tp, sB, sK, sL, out, B, K, L);
+  TATT_LAUNCH_CHECK("tp_rows");
+  return TATT_OK;
+}
+int tatt_pe_dropout(const float* pe, float* pos, int B, int L, uint32_t seed_site, uint32_t thresh, float scale, hipStream_t st) {
+  DropCfg dc{seed_site, thresh, scale};
+  hipLaunchKernelGGL(pe_dropout_k, GRID1D((long)B * L * 64), 0, st, pe, pos, B, L, dc);
+  TATT_LAUNCH_CHECK("pe_dropout");
+  return TATT_OK;
+}
+int tatt_dropout_mul(const float* x, float* y, long n, uint32_t seed_site, uint32_t thresh, float scale, hipStream_t st) {
+  DropCfg dc{seed_site, thresh, scale};
+  hipLaunchKernelGGL(dropout_mul_k, GRID1D(n), 0, st, x, y, n, dc);
+  TATT_LAUNCH_CHECK("dropout_mul");
+  return TATT_OK;
+}
+int tatt_relu_drop_bwd(const float* h, const float* dh, float* out, long n, uint32_t seed_site, uint32_t thresh, float scale,
+                       hipStream_t st) {
+  DropCfg dc{seed_site, thresh, scale};
+  hipLaunchKernelGGL(relu_drop_bwd_k, GRID1D(n), 0, st, h, dh, out, n, dc);
+  TATT_LAUNCH_CHECK("relu_drop_bwd");
+  return TATT_OK;
+}
+
+}  // extern "C"

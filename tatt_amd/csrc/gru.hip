@@ -1,0 +1,265 @@
+// GRU recurrences.
+//  (1) small BiGRU of the SRBs (hidden 32): one half-wave (32 lanes) per (sequence, direction); lane j owns
+//      hidden unit j, keeps its three W_hh rows (96 floats) in VGPRs, h is broadcast through LDS.
+//      The time-parallel input projection gi = W_ih x + b_ih is a GEMM done by the caller.
+//  (2) RPE GRU of the TP interpreter (hidden 512, 64 rows, recurrence over the batch axis): per step the
+//      h*W_hh^T product is a GEMM launched by the caller; the element-wise gate kernels live here.
+// Gate order (r, z, n):  r = s(gi_r+gh_r)  z = s(gi_z+gh_z)  n = tanh(gi_n + r*gh_n)  h' = (1-z) n + z h.
+#include "common.h"
+
+namespace {
+
+constexpr int HID = 32;
+
+struct SeqMap {  // pixel index of (sequence s, step t) = (s / inner) * outer_stride + (s % inner) * inner_stride + t * tstride
+  int inner;
+  long outer_stride, inner_stride, tstride;
+  int T;
+};
+
+__device__ __forceinline__ long seq_base(const SeqMap& m, int s) {
+  int so = s / m.inner, si = s - so * m.inner;
+  return (long)so * m.outer_stride + (long)si * m.inner_stride;
+}
+
+// gi [P,192] (dir*96 + gate*32 + j); whh/bhh: per-direction pointers; out [P,64]; save [P,2,4,32] or null
+__global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, const float* __restrict__ whh_f,
+                                                 const float* __restrict__ whh_b, const float* __restrict__ bhh_f,
+                                                 const float* __restrict__ bhh_b, float* __restrict__ out,
+                                                 float* __restrict__ save, int nseq, SeqMap sm) {
+  __shared__ __attribute__((aligned(16))) float hbuf[8][HID];
+  const int tid = threadIdx.x, j = tid & 31, slot = tid >> 5;
+  int wi = blockIdx.x * 8 + slot;
+  const bool active = wi < nseq * 2;
+  if (!active) wi = nseq * 2 - 1;
+  const int s = wi >> 1, dir = wi & 1;
+  const float* whh = dir ? whh_b : whh_f;
+  const float* bhh = dir ? bhh_b : bhh_f;
+  float wr[HID], wz[HID], wn[HID];
+#pragma unroll
+  for (int k = 0; k < HID; ++k) {
+    wr[k] = whh[(0 * HID + j) * HID + k];
+    wz[k] = whh[(1 * HID + j) * HID + k];
+    wn[k] = whh[(2 * HID + j) * HID + k];
+  }
+  const float br = bhh[j], bz = bhh[HID + j], bn = bhh[2 * HID + j];
+  const long base = seq_base(sm, s);
+  float h = 0.f;
+  hbuf[slot][j] = 0.f;
+  const int T = sm.T;
+  long pix = base + (long)(dir ? T - 1 : 0) * sm.tstride;
+  const long pstep = dir ? -sm.tstride : sm.tstride;
+  float g_r = gi[pix * 192 + dir * 96 + j], g_z = gi[pix * 192 + dir * 96 + HID + j], g_n = gi[pix * 192 + dir * 96 + 2 * HID + j];
+  for (int t = 0; t < T; ++t) {
+    float nr = 0.f, nz = 0.f, nn = 0.f;
+    if (t + 1 < T) {  // prefetch next step's input projection
+      long np = pix + pstep;
+      nr = gi[np * 192 + dir * 96 + j];
+      nz = gi[np * 192 + dir * 96 + HID + j];
+      nn = gi[np * 192 + dir * 96 + 2 * HID + j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float ar = br, az = bz, an = bn;
+#pragma unroll
+    for (int k4 = 0; k4 < HID / 4; ++k4) {
+      float4 hv = *reinterpret_cast<const float4*>(&hbuf[slot][k4 * 4]);
+      ar += wr[k4 * 4] * hv.x + wr[k4 * 4 + 1] * hv.y + wr[k4 * 4 + 2] * hv.z + wr[k4 * 4 + 3] * hv.w;
+      az += wz[k4 * 4] * hv.x + wz[k4 * 4 + 1] * hv.y + wz[k4 * 4 + 2] * hv.z + wz[k4 * 4 + 3] * hv.w;
+      an += wn[k4 * 4] * hv.x + wn[k4 * 4 + 1] * hv.y + wn[k4 * 4 + 2] * hv.z + wn[k4 * 4 + 3] * hv.w;
+    }
+    float r = sigmoidf_(g_r + ar), z = sigmoidf_(g_z + az);
+    float n = tanhf(g_n + r * an);
+    h = (1.f - z) * n + z * h;
+    __builtin_amdgcn_wave_barrier();
+    hbuf[slot][j] = h;
+    if (active) {
+      out[pix * 64 + dir * HID + j] = h;
+      if (save) {
+        float* sp = save + (pix * 2 + dir) * 4 * HID;
+        sp[j] = r;
+        sp[HID + j] = z;
+        sp[2 * HID + j] = n;
+        sp[3 * HID + j] = an;
+      }
+    }
+    pix += pstep;
+    g_r = nr; g_z = nz; g_n = nn;
+  }
+}
+
+// BPTT. dout [P,64]; out [P,64] (forward output, gives h_prev); save [P,2,4,32];
+// writes dgi [P,192] (dr,dz,dn), dgh [P,192] (dr,dz,dn*r), hprev [P,64].
+__global__ __launch_bounds__(256) void gru32_bwd(const float* __restrict__ dout, const float* __restrict__ out,
+                                                 const float* __restrict__ save, const float* __restrict__ whh_f,
+                                                 const float* __restrict__ whh_b, float* __restrict__ dgi,
+                                                 float* __restrict__ dgh, float* __restrict__ hprev_out, int nseq, SeqMap sm) {
+  __shared__ __attribute__((aligned(16))) float gbuf[8][3 * HID];
+  const int tid = threadIdx.x, j = tid & 31, slot = tid >> 5;
+  int wi = blockIdx.x * 8 + slot;
+  const bool active = wi < nseq * 2;
+  if (!active) wi = nseq * 2 - 1;
+  const int s = wi >> 1, dir = wi & 1;
+  const float* whh = dir ? whh_b : whh_f;
+  float wc[3 * HID];  // column j of W_hh
+#pragma unroll
+  for (int i = 0; i < 3 * HID; ++i) wc[i] = whh[i * HID + j];
+  const long base = seq_base(sm, s);
+  const int T = sm.T;
+  // forward order for dir 0 is t=0..T-1, so BPTT visits T-1..0; for dir 1 the reverse.
+  long pix = base + (long)(dir ? 0 : T - 1) * sm.tstride;
+  const long pstep = dir ? sm.tstride : -sm.tstride;  // towards the forward-order predecessor
+  float dh = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float* sp = save + (pix * 2 + dir) * 4 * HID;
+    float r = sp[j], z = sp[HID + j], n = sp[2 * HID + j], ghn = sp[3 * HID + j];
+    float hp = (t + 1 < T) ? out[(pix + pstep) * 64 + dir * HID + j] : 0.f;
+    float d = dh + dout[pix * 64 + dir * HID + j];
+    float dn = d * (1.f - z) * (1.f - n * n);
+    float dz = d * (hp - n) * z * (1.f - z);
+    float dr = dn * ghn * r * (1.f - r);
+    float dgn = dn * r;
+    __builtin_amdgcn_wave_barrier();
+    gbuf[slot][j] = dr;
+    gbuf[slot][HID + j] = dz;
+    gbuf[slot][2 * HID + j] = dgn;
+    if (active) {
+      float* gi_o = dgi + pix * 192 + dir * 96;
+      float* gh_o = dgh + pix * 192 + dir * 96;
+      gi_o[j] = dr; gi_o[HID + j] = dz; gi_o[2 * HID + j] = dn;
+      gh_o[j] = dr; gh_o[HID + j] = dz; gh_o[2 * HID + j] = dgn;
+      hprev_out[pix * 64 + dir * HID + j] = hp;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float acc = d * z;
+#pragma unroll
+    for (int i4 = 0; i4 < 3 * HID / 4; ++i4) {
+      float4 gv = *reinterpret_cast<const float4*>(&gbuf[slot][i4 * 4]);
+      acc += wc[i4 * 4] * gv.x + wc[i4 * 4 + 1] * gv.y + wc[i4 * 4 + 2] * gv.z + wc[i4 * 4 + 3] * gv.w;
+    }
+    dh = acc;
+    pix += pstep;
+  }
+}
+
+// ---- RPE GRU (hidden 512, 64 rows w, both directions) ---------------------------------------------------------
+// layouts: gi [2][64][1536] (time invariant); gh [2][64][1536] (this step, bias included); h buffers [2][64][512].
+// query_pos is NHWC [B][16][64][64]; feature f = dir*512 + j -> (hh = f/64, c = f%64); time index of step s is
+// s for dir 0 and B-1-s for dir 1.
+constexpr int RH = 512, RW = 64;
+
+__global__ void rpe_gate_fwd(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ bhh_f,
+                             const float* __restrict__ bhh_b, const float* __restrict__ hprev, float* __restrict__ hout,
+                             float* __restrict__ qp, int s, int B, long dir_stride_gh, long dir_stride_h) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;  // (dir, w, j)
+  if (i >= 2 * RW * RH) return;
+  int j = i % RH, w = (i / RH) % RW, dir = i / (RH * RW);
+  const float* g_i = gi + ((long)dir * RW + w) * 3 * RH;
+  const float* g_h = gh + dir * dir_stride_gh + (long)w * 3 * RH;
+  const float* bh = dir ? bhh_b : bhh_f;
+  float hp = hprev[dir * dir_stride_h + (long)w * RH + j];
+  float r = sigmoidf_(g_i[j] + g_h[j] + bh[j]);
+  float z = sigmoidf_(g_i[RH + j] + g_h[RH + j] + bh[RH + j]);
+  float n = tanhf(g_i[2 * RH + j] + r * (g_h[2 * RH + j] + bh[2 * RH + j]));
+  float h = (1.f - z) * n + z * hp;
+  hout[dir * dir_stride_h + (long)w * RH + j] = h;
+  int tt = dir ? B - 1 - s : s;
+  int f = dir * RH + j;
+  qp[(((long)tt * 16 + (f >> 6)) * RW + w) * 64 + (f & 63)] = h;
+}
+
+// carry [2][64][512]: on entry dL/dh_s (recurrent part), on exit dh*z (the caller's GEMM then adds dgh*W_hh)
+__global__ void rpe_gate_bwd(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ bhh_f,
+                             const float* __restrict__ bhh_b, const float* __restrict__ hprev, const float* __restrict__ dqp, float* __restrict__ carry, float* __restrict__ dgh,
+                             float* __restrict__ dgi_sum, int s, int B, long dir_stride_gh, long dir_stride_h) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * RW * RH) return;
+  int j = i % RH, w = (i / RH) % RW, dir = i / (RH * RW);
+  const float* g_i = gi + ((long)dir * RW + w) * 3 * RH;
+  const float* g_h = gh + dir * dir_stride_gh + (long)w * 3 * RH;
+  const float* bh = dir ? bhh_b : bhh_f;
+  float hp = hprev[dir * dir_stride_h + (long)w * RH + j];
+  float ghn = g_h[2 * RH + j] + bh[2 * RH + j];
+  float r = sigmoidf_(g_i[j] + g_h[j] + bh[j]);
+  float z = sigmoidf_(g_i[RH + j] + g_h[RH + j] + bh[RH + j]);
+  float n = tanhf(g_i[2 * RH + j] + r * ghn);
+  int tt = dir ? B - 1 - s : s;
+  int f = dir * RH + j;
+  long ci = ((long)dir * RW + w) * RH + j;
+  float d = carry[ci] + dqp[(((long)tt * 16 + (f >> 6)) * RW + w) * 64 + (f & 63)];
+  float dn = d * (1.f - z) * (1.f - n * n);
+  float dz = d * (hp - n) * z * (1.f - z);
+  float dr = dn * ghn * r * (1.f - r);
+  float* o = dgh + dir * dir_stride_gh + (long)w * 3 * RH;
+  o[j] = dr; o[RH + j] = dz; o[2 * RH + j] = dn * r;
+  float* gs = dgi_sum + ((long)dir * RW + w) * 3 * RH;
+  gs[j] += dr; gs[RH + j] += dz; gs[2 * RH + j] += dn;
+  carry[ci] = d * z;
+}
+
+// x[w][hh*64+c] = init_factor[(hh*64+w)*64 + c]  (transformer_v2.py:215-217 with identical rows over the batch)
+__global__ void rpe_gather_x(const float* __restrict__ init_factor, float* __restrict__ x) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= RW * 1024) return;
+  int f = i % 1024, w = i / 1024;
+  x[i] = init_factor[((long)(f >> 6) * RW + w) * 64 + (f & 63)];
+}
+__global__ void rpe_scatter_dx(const float* __restrict__ dx, float* __restrict__ dinit, int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= RW * 1024) return;
+  int f = i % 1024, w = i / 1024;
+  long o = ((long)(f >> 6) * RW + w) * 64 + (f & 63);
+  dinit[o] = accumulate ? dinit[o] + dx[i] : dx[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* out,
+                   float* save, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride, hipStream_t st) {
+  TATT_CHECK_ARG(nseq > 0 && T > 0 && inner > 0, "tatt_gru32_fwd: bad dims");
+  SeqMap sm{inner, outer_stride, inner_stride, tstride, T};
+  hipLaunchKernelGGL(gru32_fwd, dim3(cdiv(nseq * 2, 8)), dim3(256), 0, st, gi, whh_f, whh_b, bhh_f, bhh_b, out, save, nseq, sm);
+  TATT_LAUNCH_CHECK("gru32_fwd");
+  return TATT_OK;
+}
+
+int tatt_gru32_bwd(const float* dout, const float* out, const float* save, const float* whh_f, const float* whh_b, float* dgi,
+                   float* dgh, float* hprev, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride,
+                   hipStream_t st) {
+  TATT_CHECK_ARG(nseq > 0 && T > 0 && inner > 0, "tatt_gru32_bwd: bad dims");
+  SeqMap sm{inner, outer_stride, inner_stride, tstride, T};
+  hipLaunchKernelGGL(gru32_bwd, dim3(cdiv(nseq * 2, 8)), dim3(256), 0, st, dout, out, save, whh_f, whh_b, dgi, dgh, hprev, nseq, sm);
+  TATT_LAUNCH_CHECK("gru32_bwd");
+  return TATT_OK;
+}
+
+int tatt_rpe_gate_fwd(const float* gi, const float* gh, const float* bhh_f, const float* bhh_b, const float* hprev, float* hout,
+                      float* qp, int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t st) {
+  hipLaunchKernelGGL(rpe_gate_fwd, dim3(cdiv(2 * RW * RH, 256)), dim3(256), 0, st, gi, gh, bhh_f, bhh_b, hprev, hout, qp, s, B,
+                     dir_stride_gh, dir_stride_h);
+  TATT_LAUNCH_CHECK("rpe_gate_fwd");
+  return TATT_OK;
+}
+
+int tatt_rpe_gate_bwd(const float* gi, const float* gh, const float* bhh_f, const float* bhh_b, const float* hprev,
+                      const float* dqp, float* carry, float* dgh, float* dgi_sum, int s, int B, long dir_stride_gh,
+                      long dir_stride_h, hipStream_t st) {
+  hipLaunchKernelGGL(rpe_gate_bwd, dim3(cdiv(2 * RW * RH, 256)), dim3(256), 0, st, gi, gh, bhh_f, bhh_b, hprev, dqp, carry, dgh,
+                     dgi_sum, s, B, dir_stride_gh, dir_stride_h);
+  TATT_LAUNCH_CHECK("rpe_gate_bwd");
+  return TATT_OK;
+}
+
+int tatt_rpe_gather_x(const float* init_factor, float* x, hipStream_t st) {
+  hipLaunchKernelGGL(rpe_gather_x, dim3(cdiv(RW * 1024, 256)), dim3(256), 0, st, init_factor, x);
+  TATT_LAUNCH_CHECK("rpe_gather_x");
+  return TATT_OK;
+}
+int tatt_rpe_scatter_dx(const float* dx, float* dinit, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(rpe_scatter_dx, dim3(cdiv(RW * 1024, 256)), dim3(256), 0, st, dx, dinit, accumulate);
+  TATT_LAUNCH_CHECK("rpe_scatter_dx");
+  return TATT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,351 @@
+// BatchNorm (training/eval, NHWC rows x C) and LayerNorm (C = 64, one wave per row) kernels, fwd + bwd.
+#include "common.h"
+
+namespace {
+
+constexpr int BN_MAXBLK = 256;
+
+// ---- BatchNorm statistics: per-block (mean, M2) over a row range, merged with Chan's formula -------------
+// partial layout: [nblk][2][C]
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, long ldx, int R, int C, int rows_per_blk,
+                                                        float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int CT = C < 256 ? C : 256, RL = 256 / CT;
+  const int tid = threadIdx.x, cl = tid % CT, rl = tid / CT;
+  const int rb = blockIdx.x * rows_per_blk, re = min(R, rb + rows_per_blk);
+  const int cnt = re - rb;
+  for (int c = cl; c < C; c += CT) {
+    float s = 0.f;
+    if (rl < RL)
+      for (int r = rb + rl; r < re; r += RL) s += x[(long)r * ldx + c];
+    red[tid] = (rl < RL) ? s : 0.f;
+    __syncthreads();
+    float tot = 0.f;
+    for (int j = 0; j < RL; ++j) tot += red[j * CT + cl];
+    float mean = tot / (float)cnt;
+    __syncthreads();
+    float m2 = 0.f;
+    if (rl < RL)
+      for (int r = rb + rl; r < re; r += RL) {
+        float d = x[(long)r * ldx + c] - mean;
+        m2 += d * d;
+      }
+    red[tid] = (rl < RL) ? m2 : 0.f;
+    __syncthreads();
+    if (rl == 0) {
+      float t2 = 0.f;
+      for (int j = 0; j < RL; ++j) t2 += red[j * CT + cl];
+      partial[((long)blockIdx.x * 2 + 0) * C + c] = mean;
+      partial[((long)blockIdx.x * 2 + 1) * C + c] = t2;
+    }
+    __syncthreads();
+  }
+}
+
+// stat layout: [2][C] = mean, invstd.  running stats updated with momentum (unbiased var).
+__global__ void bn_stats_final(const float* __restrict__ partial, int nblk, int R, int C, int rows_per_blk, float eps,
+                               float momentum, float* __restrict__ stat, float* __restrict__ run_mean,
+                               float* __restrict__ run_var) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int b = 0; b < nblk; ++b) {
+    float nb = (float)(min(R, (b + 1) * rows_per_blk) - b * rows_per_blk);
+    float mb = partial[((long)b * 2 + 0) * C + c], m2b = partial[((long)b * 2 + 1) * C + c];
+    float d = mb - mean, nn = n + nb;
+    mean += d * (nb / nn);
+    m2 += m2b + d * d * (n * nb / nn);
+    n = nn;
+  }
+  float var = m2 / n;
+  stat[c] = mean;
+  stat[C + c] = rsqrtf(var + eps);
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+    float unb = n > 1.f ? m2 / (n - 1.f) : var;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+  }
+}
+
+// eval mode: stat from running stats
+__global__ void bn_stat_from_running(const float* __restrict__ rm, const float* __restrict__ rv, int C, float eps,
+                                     float* __restrict__ stat) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  stat[c] = rm[c];
+  stat[C + c] = rsqrtf(rv[c] + eps);
+}
+
+// act: 0 none, 1 relu, 2 mish.  y = act(bn(x)) (+ res)
+__global__ void bn_apply_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ stat,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res,
+                                long ldr, float* __restrict__ y, long ldy, int R, int C, int act) {
+  const int c4 = C >> 2;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)R * c4) return;
+  int r = (int)(i / c4), c = (int)(i - (long)r * c4) * 4;
+  float4 v = *reinterpret_cast<const float4*>(x + (long)r * ldx + c);
+  float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float t = (in[e] - stat[c + e]) * stat[C + c + e] * gamma[c + e] + beta[c + e];
+    if (act == 1) t = fmaxf(t, 0.f);
+    else if (act == 2) t = mishf_(t);
+    out[e] = t;
+  }
+  if (res) {
+    float4 rr = *reinterpret_cast<const float4*>(res + (long)r * ldr + c);
+    out[0] += rr.x; out[1] += rr.y; out[2] += rr.z; out[3] += rr.w;
+  }
+  *reinterpret_cast<float4*>(y + (long)r * ldy + c) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+__device__ __forceinline__ float act_grad(float t, int act) {
+  if (act == 1) return t > 0.f ? 1.f : 0.f;
+  if (act == 2) return mish_gradf_(t);
+  return 1.f;
+}
+
+// partial sums of g = dy*act'(bn(x)) and g*xhat : partial [nblk][2][C]
+__global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy,
+                                                     const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int R, int C, int act, int rows_per_blk,
+                                                     float* __restrict__ partial) {
+  __shared__ float red[2][256];
+  const int CT = C < 256 ? C : 256, RL = 256 / CT;
+  const int tid = threadIdx.x, cl = tid % CT, rl = tid / CT;
+  const int rb = blockIdx.x * rows_per_blk, re = min(R, rb + rows_per_blk);
+  for (int c = cl; c < C; c += CT) {
+    float s1 = 0.f, s2 = 0.f;
+    if (rl < RL) {
+      float mean = stat[c], inv = stat[C + c], ga = gamma[c], be = beta[c];
+      for (int r = rb + rl; r < re; r += RL) {
+        float xh = (x[(long)r * ldx + c] - mean) * inv;
+        float g = dy[(long)r * lddy + c] * act_grad(xh * ga + be, act);
+        s1 += g;
+        s2 += g * xh;
+      }
+    }
+    red[0][tid] = s1;
+    red[1][tid] = s2;
+    __syncthreads();
+    if (rl == 0) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int j = 0; j < RL; ++j) {
+        t1 += red[0][j * CT + cl];
+        t2 += red[1][j * CT + cl];
+      }
+      partial[((long)blockIdx.x * 2 + 0) * C + c] = t1;
+      partial[((long)blockIdx.x * 2 + 1) * C + c] = t2;
+    }
+    __syncthreads();
+  }
+}
+
+// sums[2][C]; dgamma/dbeta (+)=
+__global__ void bn_bwd_final(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums,
+                             float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = 0; b < nblk; ++b) {
+    s1 += partial[((long)b * 2 + 0) * C + c];
+    s2 += partial[((long)b * 2 + 1) * C + c];
+  }
+  sums[c] = s1;
+  sums[C + c] = s2;
+  if (dgamma) {
+    dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
+    dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
+  }
+}
+
+// dx = gamma*invstd*(g - s1/R - xhat*s2/R) in training mode; eval mode (train=0): dx = gamma*invstd*g
+__global__ void bn_bwd_apply(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy,
+                             const float* __restrict__ stat, const float* __restrict__ gamma, const float* __restrict__ beta,
+                             const float* __restrict__ sums, float* __restrict__ dx, long lddx, int R, int C, int act, int train,
+                             int accumulate) {
+  const int c4 = C >> 2;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)R * c4) return;
+  int r = (int)(i / c4), c = (int)(i - (long)r * c4) * 4;
+  float4 xv = *reinterpret_cast<const float4*>(x + (long)r * ldx + c);
+  float4 gv = *reinterpret_cast<const float4*>(dy + (long)r * lddy + c);
+  float xi[4] = {xv.x, xv.y, xv.z, xv.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w}, o[4];
+  const float invR = 1.f / (float)R;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float mean = stat[c + e], inv = stat[C + c + e], ga = gamma[c + e];
+    float xh = (xi[e] - mean) * inv;
+    float g = gi[e] * act_grad(xh * ga + beta[c + e], act);
+    float t = train ? (g - sums[c + e] * invR - xh * sums[C + c + e] * invR) : g;
+    o[e] = ga * inv * t;
+  }
+  float* d = dx + (long)r * lddx + c;
+  if (accumulate) {
+    float4 p = *reinterpret_cast<const float4*>(d);
+    o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w;
+  }
+  *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// ---- LayerNorm over 64 channels: one wave per row, lane = channel ------------------------------------------
+// v = x + dropmask*res (res optional, drop index = row*64 + c) ; y = LN(v)*gamma + beta ; vout (optional) = v
+// optional second output: y2 accumulation  yacc = yscale * y (+ yacc)  (used for the mean over decoder layers)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, DropCfg dc,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ vout, float* __restrict__ y, int rows, float eps) {
+  const int lane = threadIdx.x & 63;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  long i = (long)row * 64 + lane;
+  float v = x[i];
+  if (res) v += res[i] * tatt_drop_mask(dc.seed_site, (uint32_t)i, dc.thresh, dc.scale);
+  float mean = wave_sum(v) * (1.f / 64.f);
+  float d = v - mean;
+  float var = wave_sum(d * d) * (1.f / 64.f);
+  float rstd = rsqrtf(var + eps);
+  if (vout) vout[i] = v;
+  y[i] = d * rstd * gamma[lane] + beta[lane];
+}
+
+// dv = rstd*(gamma*dy - mean(gamma*dy) - xhat*mean(gamma*dy*xhat)); dv (+)= ; partial dgamma/dbeta per block.
+// dres (optional) = dv_this * dropmask  (written, not accumulated)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ v, const float* __restrict__ dy, float dyscale,
+                                                     const float* __restrict__ gamma, float* __restrict__ dv, int dv_accumulate,
+                                                     float* __restrict__ dres, DropCfg dc, float* __restrict__ partial, int rows,
+                                                     int rows_per_blk, float eps) {
+  __shared__ float red[2][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int rb = blockIdx.x * rows_per_blk, re = min(rows, rb + rows_per_blk);
+  const float ga = gamma[lane];
+  float sg = 0.f, sb = 0.f;
+  for (int row = rb + w; row < re; row += 4) {
+    long i = (long)row * 64 + lane;
+    float vv = v[i];
+    float mean = wave_sum(vv) * (1.f / 64.f);
+    float d = vv - mean;
+    float var = wave_sum(d * d) * (1.f / 64.f);
+    float rstd = rsqrtf(var + eps);
+    float xh = d * rstd;
+    float g = dy[i] * dyscale;
+    sg += g * xh;
+    sb += g;
+    float gg = g * ga;
+    float m1 = wave_sum(gg) * (1.f / 64.f);
+    float m2 = wave_sum(gg * xh) * (1.f / 64.f);
+    float o = rstd * (gg - m1 - xh * m2);
+    if (dres) dres[i] = o * tatt_drop_mask(dc.seed_site, (uint32_t)i, dc.thresh, dc.scale);
+    if (dv_accumulate) o += dv[i];
+    dv[i] = o;
+  }
+  red[0][threadIdx.x] = sg;
+  red[1][threadIdx.x] = sb;
+  __syncthreads();
+  if (w == 0) {
+    float a = red[0][lane] + red[0][64 + lane] + red[0][128 + lane] + red[0][192 + lane];
+    float b = red[1][lane] + red[1][64 + lane] + red[1][128 + lane] + red[1][192 + lane];
+    partial[((long)blockIdx.x * 2 + 0) * 64 + lane] = a;
+    partial[((long)blockIdx.x * 2 + 1) * 64 + lane] = b;
+  }
+}
+
+__global__ void ln_bwd_final(const float* __restrict__ partial, int nblk, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                             int accumulate) {
+  int c = threadIdx.x;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nblk; ++k) {
+    a += partial[((long)k * 2 + 0) * 64 + c];
+    b += partial[((long)k * 2 + 1) * 64 + c];
+  }
+  dgamma[c] = accumulate ? dgamma[c] + a : a;
+  dbeta[c] = accumulate ? dbeta[c] + b : b;
+}
+
+inline void bn_blocking(int R, int* nblk, int* rpb) {
+  int rows_per_blk = R >= 64 * BN_MAXBLK ? cdiv(R, BN_MAXBLK) : 64;
+  *rpb = rows_per_blk;
+  *nblk = cdiv(R, rows_per_blk);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t tatt_bn_workspace(int C) { return (size_t)BN_MAXBLK * 2 * C + 2 * C; }
+
+// training: batch statistics of x [R,C] -> stat[2][C] (mean, invstd), running stats updated in place.
+int tatt_bn_stats(const float* x, long ldx, int R, int C, float eps, float momentum, float* stat, float* run_mean, float* run_var,
+                  float* workspace, hipStream_t st) {
+  TATT_CHECK_ARG(R > 0 && C > 0 && (C <= 256 || C % 256 == 0), "tatt_bn_stats: bad dims R=%d C=%d", R, C);
+  int nblk, rpb;
+  bn_blocking(R, &nblk, &rpb);
+  hipLaunchKernelGGL(bn_stats_partial, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, rpb, workspace);
+  TATT_LAUNCH_CHECK("bn_stats_partial");
+  hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, 64)), dim3(64), 0, st, workspace, nblk, R, C, rpb, eps, momentum, stat, run_mean,
+                     run_var);
+  TATT_LAUNCH_CHECK("bn_stats_final");
+  return TATT_OK;
+}
+
+int tatt_bn_stat_from_running(const float* rm, const float* rv, int C, float eps, float* stat, hipStream_t st) {
+  hipLaunchKernelGGL(bn_stat_from_running, dim3(cdiv(C, 64)), dim3(64), 0, st, rm, rv, C, eps, stat);
+  TATT_LAUNCH_CHECK("bn_stat_from_running");
+  return TATT_OK;
+}
+
+int tatt_bn_apply(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr,
+                  float* y, long ldy, int R, int C, int act, hipStream_t st) {
+  TATT_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "tatt_bn_apply: C/ld must be multiples of 4");
+  long tot = (long)R * (C / 4);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, x, ldx, stat, gamma, beta, res, ldr, y, ldy, R, C, act);
+  TATT_LAUNCH_CHECK("bn_apply");
+  return TATT_OK;
+}
+
+// Backward through y = act(bn(x)).  workspace: tatt_bn_workspace(C) floats.
+int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const float* stat, const float* gamma, const float* beta,
+                float* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int act, int train, int accumulate_params,
+                int accumulate_dx, float* workspace, hipStream_t st) {
+  TATT_CHECK_ARG(C % 4 == 0 && (C <= 256 || C % 256 == 0), "tatt_bn_bwd: bad C");
+  int nblk, rpb;
+  bn_blocking(R, &nblk, &rpb);
+  float* sums = workspace + (size_t)BN_MAXBLK * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_reduce, dim3(nblk), dim3(256), 0, st, x, ldx, dy, lddy, stat, gamma, beta, R, C, act, rpb, workspace);
+  TATT_LAUNCH_CHECK("bn_bwd_reduce");
+  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 64)), dim3(64), 0, st, workspace, nblk, C, sums, dgamma, dbeta, accumulate_params);
+  TATT_LAUNCH_CHECK("bn_bwd_final");
+  long tot = (long)R * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply, dim3(cdiv(tot, 256)), dim3(256), 0, st, x, ldx, dy, lddy, stat, gamma, beta, sums, dx, lddx, R, C,
+                     act, train, accumulate_dx);
+  TATT_LAUNCH_CHECK("bn_bwd_apply");
+  return TATT_OK;
+}
+
+int tatt_ln_fwd(const float* x, const float* res, uint32_t seed_site, uint32_t thresh, float scale, const float* gamma,
+                const float* beta, float* vout, float* y, int rows, float eps, hipStream_t st) {
+  DropCfg dc{seed_site, thresh, scale};
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, res, dc, gamma, beta, vout, y, rows, eps);
+  TATT_LAUNCH_CHECK("ln_fwd");
+  return TATT_OK;
+}
+
+size_t tatt_ln_workspace(int rows) { (void)rows; return (size_t)512 * 128; }
+
+int tatt_ln_bwd(const float* v, const float* dy, float dyscale, const float* gamma, float* dv, int dv_accumulate, float* dres,
+                uint32_t seed_site, uint32_t thresh, float scale, float* dgamma, float* dbeta, int accumulate_params, int rows,
+                float eps, float* workspace, hipStream_t st) {
+  DropCfg dc{seed_site, thresh, scale};
+  int nblk = cdiv(rows, 64);
+  if (nblk > 512) nblk = 512;
+  int rpb = cdiv(rows, nblk);
+  nblk = cdiv(rows, rpb);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, st, v, dy, dyscale, gamma, dv, dv_accumulate, dres, dc, workspace, rows,
+                     rpb, eps);
+  TATT_LAUNCH_CHECK("ln_bwd");
+  hipLaunchKernelGGL(ln_bwd_final, dim3(1), dim3(64), 0, st, workspace, nblk, dgamma, dbeta, accumulate_params);
+  TATT_LAUNCH_CHECK("ln_bwd_final");
+  return TATT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// TPS rectification (grid build + bilinear gather), TSC rotation sampler, ImageLoss (MSE + gradient prior)
+// and the fused clip-grad-norm + Adam optimiser step.
+#include "common.h"
+
+namespace {
+
+// ---- bilinear sampling helpers (grid_sample: bilinear, zeros padding, align_corners=False) -------------------
+struct Bilin {
+  int x0, y0;
+  float fx, fy;  // fractional parts
+};
+__device__ __forceinline__ Bilin bilin_setup(float gx, float gy, int H, int W) {
+  float ix = ((gx + 1.f) * W - 1.f) * 0.5f, iy = ((gy + 1.f) * H - 1.f) * 0.5f;
+  float x0 = floorf(ix), y0 = floorf(iy);
+  return Bilin{(int)x0, (int)y0, ix - x0, iy - y0};
+}
+__device__ __forceinline__ float tap(const float* __restrict__ img, int y, int x, int H, int W) {
+  return (x >= 0 && x < W && y >= 0 && y < H) ? img[y * W + x] : 0.f;
+}
+
+// TPS: src[b,p,:] = sum_j T[p,j] * ctrl[b,j,:]  (T = target_coordinate_repr @ inverse_kernel[:, :20], [HW,20]);
+// grid = 2*clamp(src,0,1)-1 ; y NHWC [B,H,W,C] = bilinear(x NCHW [B,C,H,W], grid)
+__global__ void tps_sample_fwd_k(const float* __restrict__ x, const float* __restrict__ ctrl, const float* __restrict__ T,
+                                 float* __restrict__ y, float* __restrict__ src_out, int B, int C, int H, int W) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H * W) return;
+  int p = i % (H * W), b = i / (H * W);
+  float sx = 0.f, sy = 0.f;
+  for (int j = 0; j < 20; ++j) {
+    float t = T[p * 20 + j];
+    sx += t * ctrl[(b * 20 + j) * 2];
+    sy += t * ctrl[(b * 20 + j) * 2 + 1];
+  }
+  if (src_out) {
+    src_out[(long)i * 2] = sx;
+    src_out[(long)i * 2 + 1] = sy;
+  }
+  float gx = 2.f * fminf(fmaxf(sx, 0.f), 1.f) - 1.f, gy = 2.f * fminf(fmaxf(sy, 0.f), 1.f) - 1.f;
+  Bilin bl = bilin_setup(gx, gy, H, W);
+  for (int c = 0; c < C; ++c) {
+    const float* img = x + ((long)b * C + c) * H * W;
+    float v00 = tap(img, bl.y0, bl.x0, H, W), v01 = tap(img, bl.y0, bl.x0 + 1, H, W);
+    float v10 = tap(img, bl.y0 + 1, bl.x0, H, W), v11 = tap(img, bl.y0 + 1, bl.x0 + 1, H, W);
+    y[(long)i * C + c] = v00 * (1.f - bl.fx) * (1.f - bl.fy) + v01 * bl.fx * (1.f - bl.fy) + v10 * (1.f - bl.fx) * bl.fy +
+                         v11 * bl.fx * bl.fy;
+  }
+}
+
+// dctrl[b,j,:] (+)= sum_p T[p,j] * dsrc[b,p,:] ; one block per batch element (H*W <= 1024 assumed by the LDS size)
+__global__ __launch_bounds__(256) void tps_sample_bwd_k(const float* __restrict__ x, const float* __restrict__ ctrl,
+                                                        const float* __restrict__ T, const float* __restrict__ dy,
+                                                        float* __restrict__ dctrl, int C, int H, int W, int accumulate) {
+  __shared__ float ds[1024 * 2];
+  const int b = blockIdx.x, HW = H * W;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    float sx = 0.f, sy = 0.f;
+    for (int j = 0; j < 20; ++j) {
+      float t = T[p * 20 + j];
+      sx += t * ctrl[(b * 20 + j) * 2];
+      sy += t * ctrl[(b * 20 + j) * 2 + 1];
+    }
+    float gx = 2.f * fminf(fmaxf(sx, 0.f), 1.f) - 1.f, gy = 2.f * fminf(fmaxf(sy, 0.f), 1.f) - 1.f;
+    Bilin bl = bilin_setup(gx, gy, H, W);
+    float dix = 0.f, diy = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float* img = x + ((long)b * C + c) * HW;
+      float v00 = tap(img, bl.y0, bl.x0, H, W), v01 = tap(img, bl.y0, bl.x0 + 1, H, W);
+      float v10 = tap(img, bl.y0 + 1, bl.x0, H, W), v11 = tap(img, bl.y0 + 1, bl.x0 + 1, H, W);
+      float g = dy[((long)b * HW + p) * C + c];
+      dix += g * ((v01 - v00) * (1.f - bl.fy) + (v11 - v10) * bl.fy);
+      diy += g * ((v10 - v00) * (1.f - bl.fx) + (v11 - v01) * bl.fx);
+    }
+    // ix = s*W - 0.5 inside the clamp; torch.clamp passes gradient on the closed interval
+    ds[p * 2] = (sx >= 0.f && sx <= 1.f) ? dix * W : 0.f;
+    ds[p * 2 + 1] = (sy >= 0.f && sy <= 1.f) ? diy * H : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < 40) {
+    int j = threadIdx.x >> 1, xy = threadIdx.x & 1;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += T[p * 20 + j] * ds[p * 2 + xy];
+    float* d = dctrl + (b * 20 + j) * 2 + xy;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+// rotation of TSC: theta = [[cos, sin*r, 0], [-sin/r, cos, 0]], r = H/W; affine_grid (align_corners=False) + bilinear.
+// NCHW in, NCHW out.
+__global__ void rotate_fwd_k(const float* __restrict__ x, const float* __restrict__ arc, float* __restrict__ y, int B, int C, int H,
+                             int W) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H * W) return;
+  int px = i % W, py = (i / W) % H, b = i / (H * W);
+  float r = (float)H / (float)W, c = cosf(arc[b]), s = sinf(arc[b]);
+  float bx = (2.f * px + 1.f) / W - 1.f, by = (2.f * py + 1.f) / H - 1.f;
+  float gx = c * bx + s * r * by, gy = (-s / r) * bx + c * by;
+  Bilin bl = bilin_setup(gx, gy, H, W);
+  for (int ch = 0; ch < C; ++ch) {
+    const float* img = x + ((long)b * C + ch) * H * W;
+    float v00 = tap(img, bl.y0, bl.x0, H, W), v01 = tap(img, bl.y0, bl.x0 + 1, H, W);
+    float v10 = tap(img, bl.y0 + 1, bl.x0, H, W), v11 = tap(img, bl.y0 + 1, bl.x0 + 1, H, W);
+    y[((long)b * C + ch) * H * W + py * W + px] = v00 * (1.f - bl.fx) * (1.f - bl.fy) + v01 * bl.fx * (1.f - bl.fy) +
+                                                  v10 * (1.f - bl.fx) * bl.fy + v11 * bl.fx * bl.fy;
+  }
+}
+// dx (must be zeroed by the caller) += scatter of dy through the same sampling pattern
+__global__ void rotate_bwd_k(const float* __restrict__ arc, const float* __restrict__ dy, float* __restrict__ dx, int B, int C, int H,
+                             int W) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H * W) return;
+  int px = i % W, py = (i / W) % H, b = i / (H * W);
+  float r = (float)H / (float)W, c = cosf(arc[b]), s = sinf(arc[b]);
+  float bx = (2.f * px + 1.f) / W - 1.f, by = (2.f * py + 1.f) / H - 1.f;
+  float gx = c * bx + s * r * by, gy = (-s / r) * bx + c * by;
+  Bilin bl = bilin_setup(gx, gy, H, W);
+  float w00 = (1.f - bl.fx) * (1.f - bl.fy), w01 = bl.fx * (1.f - bl.fy), w10 = (1.f - bl.fx) * bl.fy, w11 = bl.fx * bl.fy;
+  for (int ch = 0; ch < C; ++ch) {
+    float g = dy[((long)b * C + ch) * H * W + py * W + px];
+    float* img = dx + ((long)b * C + ch) * H * W;
+    int x0 = bl.x0, y0 = bl.y0;
+    if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) atomicAdd(img + y0 * W + x0, g * w00);
+    if (x0 + 1 >= 0 && x0 + 1 < W && y0 >= 0 && y0 < H) atomicAdd(img + y0 * W + x0 + 1, g * w01);
+    if (x0 >= 0 && x0 < W && y0 + 1 >= 0 && y0 + 1 < H) atomicAdd(img + (y0 + 1) * W + x0, g * w10);
+    if (x0 + 1 >= 0 && x0 + 1 < W && y0 + 1 >= 0 && y0 + 1 < H) atomicAdd(img + (y0 + 1) * W + x0 + 1, g * w11);
+  }
+}
+
+// ---- ImageLoss: per-sample mean MSE over C channels + w1 * mean |g(sr)-g(hr)| over the first 3 -----------------
+__device__ __forceinline__ float gmap(const float* __restrict__ img, int y, int x, int H, int W, float* a_out, float* c_out) {
+  float r = x + 1 < W ? img[y * W + x + 1] : 0.f, l = x > 0 ? img[y * W + x - 1] : 0.f;
+  float t = y > 0 ? img[(y - 1) * W + x] : 0.f, bb = y + 1 < H ? img[(y + 1) * W + x] : 0.f;
+  float a = (r - l) * 0.5f, c = (t - bb) * 0.5f;
+  if (a_out) { *a_out = a; *c_out = c; }
+  return sqrtf(a * a + c * c + 1e-6f);
+}
+
+__global__ __launch_bounds__(256) void image_loss_fwd_k(const float* __restrict__ sr, const float* __restrict__ hr,
+                                                        float* __restrict__ per, int C, int H, int W, float w0, float w1) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x, HW = H * W;
+  float mse = 0.f, gl = 0.f;
+  for (int i = threadIdx.x; i < C * HW; i += 256) {
+    int c = i / HW, p = i - c * HW;
+    float d = sr[(long)b * C * HW + i] - hr[(long)b * C * HW + i];
+    mse += d * d;
+    if (c < 3) {
+      int y = p / W, x = p - y * W;
+      gl += fabsf(gmap(sr + ((long)b * C + c) * HW, y, x, H, W, nullptr, nullptr) -
+                  gmap(hr + ((long)b * C + c) * HW, y, x, H, W, nullptr, nullptr));
+    }
+  }
+  mse = wave_sum(mse);
+  gl = wave_sum(gl);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = mse;
+    red[1][threadIdx.x >> 6] = gl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = red[0][0] + red[0][1] + red[0][2] + red[0][3], g = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    per[b] = w0 * m / (float)(C * HW) + w1 * g / (float)(3 * HW);
+  }
+}
+
+// dsr = dper[b] * d per[b] / d sr   (dper may be null: then uniform weight `uniform`)
+__global__ void image_loss_bwd_k(const float* __restrict__ sr, const float* __restrict__ hr, const float* __restrict__ dper,
+                                 float uniform, float* __restrict__ dsr, int B, int C, int H, int W, float w0, float w1) {
+  const int HW = H * W;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C * HW) return;
+  int p = (int)(i % HW);
+  int c = (int)((i / HW) % C);
+  int b = (int)(i / ((long)C * HW));
+  float wgt = dper ? dper[b] : uniform;
+  float g = w0 * 2.f * (sr[i] - hr[i]) / (float)(C * HW);
+  if (c < 3) {
+    const float* s = sr + ((long)b * C + c) * HW;
+    const float* h = hr + ((long)b * C + c) * HW;
+    int y = p / W, x = p - y * W;
+    float acc = 0.f;
+    // this pixel is the 'r' tap of (y,x-1), the 'l' tap of (y,x+1), the 't' tap of (y+1,x), the 'b' tap of (y-1,x)
+    const int ny[4] = {y, y, y + 1, y - 1}, nx[4] = {x - 1, x + 1, x, x};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int yy = ny[k], xx = nx[k];
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      float a, cc;
+      float gs = gmap(s, yy, xx, H, W, &a, &cc), gh = gmap(h, yy, xx, H, W, nullptr, nullptr);
+      float d = gs - gh;
+      float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      float num = (k == 0) ? 0.5f * a : (k == 1) ? -0.5f * a : (k == 2) ? 0.5f * cc : -0.5f * cc;
+      acc += sg * num / gs;
+    }
+    g += w1 * acc / (float)(3 * HW);
+  }
+  dsr[i] = wgt * g;
+}
+
+// ---- optimiser: global grad norm -> clip coefficient -> Adam ------------------------------------------------
+// state floats: [0] total norm, [1] clip coef, [2] step (as float), [3] 1-b1^t, [4] 1-b2^t
+__global__ __launch_bounds__(256) void sumsq_partial_k(const float* __restrict__ g, long n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void clip_final_k(const float* __restrict__ partial, int n, float max_norm, float b1, float b2, float* __restrict__ state) {
+  if (threadIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += (double)partial[i];
+  float norm = (float)sqrt(s);
+  state[0] = norm;
+  float coef = max_norm / (norm + 1e-6f);
+  state[1] = (max_norm > 0.f) ? fminf(coef, 1.f) : 1.f;
+  float step = state[2] + 1.f;
+  state[2] = step;
+  state[3] = 1.f - powf(b1, step);
+  state[4] = 1.f - powf(b2, step);
+}
+__global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                       float lr, float b1, float b2, float eps, const float* __restrict__ state) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gg = g[i] * state[1];
+  float mm = b1 * m[i] + (1.f - b1) * gg;
+  float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+  m[i] = mm;
+  v[i] = vv;
+  float denom = sqrtf(vv) / sqrtf(state[4]) + eps;
+  p[i] -= (lr / state[3]) * (mm / denom);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tatt_tps_sample_fwd(const float* x, const float* ctrl, const float* T, float* y, float* src_out, int B, int C, int H, int W,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(tps_sample_fwd_k, dim3(cdiv((long)B * H * W, 256)), dim3(256), 0, st, x, ctrl, T, y, src_out, B, C, H, W);
+  TATT_LAUNCH_CHECK("tps_sample_fwd");
+  return TATT_OK;
+}
+int tatt_tps_sample_bwd(const float* x, const float* ctrl, const float* T, const float* dy, float* dctrl, int B, int C, int H, int W,
+                        int accumulate, hipStream_t st) {
+  TATT_CHECK_ARG(H * W <= 1024, "tatt_tps_sample_bwd: H*W must be <= 1024");
+  hipLaunchKernelGGL(tps_sample_bwd_k, dim3(B), dim3(256), 0, st, x, ctrl, T, dy, dctrl, C, H, W, accumulate);
+  TATT_LAUNCH_CHECK("tps_sample_bwd");
+  return TATT_OK;
+}
+int tatt_rotate_fwd(const float* x, const float* arc, float* y, int B, int C, int H, int W, hipStream_t st) {
+  hipLaunchKernelGGL(rotate_fwd_k, dim3(cdiv((long)B * H * W, 256)), dim3(256), 0, st, x, arc, y, B, C, H, W);
+  TATT_LAUNCH_CHECK("rotate_fwd");
+  return TATT_OK;
+}
+int tatt_rotate_bwd(const float* arc, const float* dy, float* dx, int B, int C, int H, int W, hipStream_t st) {
+  hipLaunchKernelGGL(rotate_bwd_k, dim3(cdiv((long)B * H * W, 256)), dim3(256), 0, st, arc, dy, dx, B, C, H, W);
+  TATT_LAUNCH_CHECK("rotate_bwd");
+  return TATT_OK;
+}
+int tatt_image_loss_fwd(const float* sr, const float* hr, float* per, int B, int C, int H, int W, float w0, float w1, hipStream_t st) {
+  hipLaunchKernelGGL(image_loss_fwd_k, dim3(B), dim3(256), 0, st, sr, hr, per, C, H, W, w0, w1);
+  TATT_LAUNCH_CHECK("image_loss_fwd");
+  return TATT_OK;
+}
+int tatt_image_loss_bwd(const float* sr, const float* hr, const float* dper, float uniform, float* dsr, int B, int C, int H, int W,
+                        float w0, float w1, hipStream_t st) {
+  hipLaunchKernelGGL(image_loss_bwd_k, dim3(cdiv((long)B * C * H * W, 256)), dim3(256), 0, st, sr, hr, dper, uniform, dsr, B, C, H, W,
+                     w0, w1);
+  TATT_LAUNCH_CHECK("image_loss_bwd");
+  return TATT_OK;
+}
+// workspace: 1024 floats; state: 8 floats (persistent across steps, zero-initialised by the caller)
+int tatt_clip_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float max_norm,
+                   float* state, float* workspace, hipStream_t st) {
+  int nblk = cdiv(n, 256 * 16);
+  if (nblk > 1024) nblk = 1024;
+  if (nblk < 1) nblk = 1;
+  hipLaunchKernelGGL(sumsq_partial_k, dim3(nblk), dim3(256), 0, st, g, n, workspace);
+  TATT_LAUNCH_CHECK("sumsq_partial");
+  hipLaunchKernelGGL(clip_final_k, dim3(1), dim3(64), 0, st, workspace, nblk, max_norm, b1, b2, state);
+  TATT_LAUNCH_CHECK("clip_final");
+  hipLaunchKernelGGL(adam_k, dim3(cdiv(n, 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, state);
+  TATT_LAUNCH_CHECK("adam");
+  return TATT_OK;
+}
+
+}  // extern "C"

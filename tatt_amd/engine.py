@@ -1,0 +1,618 @@
+"""Launch plan of the TATT SR network on the HIP kernels: explicit forward and hand-derived backward.
+
+Host side only: this file decides which C-ABI entry point (include/tatt_hip.h) runs on which buffer; torch is
+used for device memory and the current stream.  Activations are NHWC fp32 ("rows x channels", row = (b, y, x)),
+which makes the image tokens of the TP interpreter ([B*1024, 64]), the GRU sequences and the conv GEMMs all
+views of the same buffers.  Reference call stack: SURVEY.md §3.2 (model/tsrn.py:648-684).
+"""
+from __future__ import annotations
+
+import torch
+
+from .lib import lib
+
+DROP_SITES = {
+    "pe": 1,
+    "enc_attn": 2, "enc_drop1": 3, "enc_ffn": 4, "enc_drop2": 5,
+    "dec0_attn": 6, "dec0_drop2": 7, "dec0_ffn": 8, "dec0_drop3": 9,
+    "dec1_attn": 10, "dec1_drop2": 11, "dec1_ffn": 12, "dec1_drop3": 13,
+}
+STN_STAGES = [(0, 4, 32, (2, 2)), (2, 32, 64, (2, 2)), (4, 64, 128, (2, 2)), (6, 128, 256, (2, 2)),
+              (8, 256, 256, (1, 2)), (10, 256, 256, None)]
+WS_FLOATS = 48 * 1024 * 1024
+NODROP = (0, 0, 1.0)
+
+
+class Ctx:
+    """Saved tensors of one forward call."""
+
+    def __init__(self):
+        self.t = {}
+
+    def __getitem__(self, k):
+        return self.t[k]
+
+    def __setitem__(self, k, v):
+        self.t[k] = v
+
+
+class Engine:
+    def __init__(self, module):
+        self.m = module
+        self.L = lib()
+        self.dev = None
+        self.ws = None
+        self._names = [n for n, _ in module.named_parameters()]
+        self._ptrs = None
+        self.P = {}
+
+    # ---- parameters --------------------------------------------------------------------------------
+    def param_list(self):
+        return [p for _, p in self.m.named_parameters()]
+
+    def refresh(self):
+        ps = dict(self.m.named_parameters())
+        ptrs = tuple(p.data_ptr() for p in ps.values())
+        if ptrs != self._ptrs:
+            self.P = {k: v.data for k, v in ps.items()}
+            self.P.update({k: v for k, v in self.m.named_buffers()})
+            for k, v in self.P.items():
+                if v.is_floating_point() and (not v.is_contiguous() or v.dtype != torch.float32):
+                    raise RuntimeError(f"parameter {k} must be contiguous fp32")
+            self._ptrs = ptrs
+        else:
+            self.P.update({k: v for k, v in self.m.named_buffers()})
+        dev = next(iter(ps.values())).device
+        if self.ws is None or self.dev != dev:
+            self.dev = dev
+            self.ws = torch.empty(WS_FLOATS, device=dev, dtype=torch.float32)
+
+    def new(self, *shape):
+        return torch.empty(shape, device=self.dev, dtype=torch.float32)
+
+    def zeros(self, *shape):
+        return torch.zeros(shape, device=self.dev, dtype=torch.float32)
+
+    # ---- thin op wrappers --------------------------------------------------------------------------------
+    def _splitk(self, M, N, K):
+        tiles = -(-M // 128) * -(-N // 64)
+        s = max(1, min(K // 256, -(-768 // tiles)))
+        while s > 1 and M * N * s > WS_FLOATS:
+            s //= 2
+        return max(1, s)
+
+    def linear(self, x, W, b, out, R, N, K, ldx=None, ldw=None, ldc=None, acc=0, relu=0):
+        """out[R,N] (+)= x[R,K] @ W[N,K]^T + b"""
+        self.L.gemm(x, W, out, b, R, N, K, ldx or K, 1, ldw or K, 1, ldc or N, 1, 0, 0, 0, acc, relu, 1, None)
+
+    def linear_dx(self, dy, W, dx, R, N, K, lddy=None, ldw=None, lddx=None, acc=0):
+        """dx[R,K] (+)= dy[R,N] @ W[N,K]"""
+        self.L.gemm(dy, W, dx, None, R, K, N, lddy or N, 1, 1, ldw or K, lddx or K, 1, 0, 0, 0, acc, 0, 1, None)
+
+    def linear_dw(self, dy, x, dW, R, N, K, lddy=None, ldx=None, lddw=None):
+        """dW[N,K] += dy[R,N]^T @ x[R,K]  (always accumulates into the gradient buffer)"""
+        sk = self._splitk(N, K, R)
+        self.L.gemm(dy, x, dW, None, N, K, R, 1, lddy or N, 1, ldx or K, lddw or K, 1, 0, 0, 0, 1, 0, sk,
+                    self.ws if sk > 1 else None)
+
+    def colsum(self, x, R, C, out, ld=None):
+        self.L.colsum(x, ld or C, R, C, out, 1, self.ws)
+
+    def conv(self, x, W, b, out, B, H, Wd, Cin, Cout, k, acc=0, relu=0):
+        T = k * k
+        self.L.conv_fwd(x, W, b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout, Cin * T, T, 0, 1, acc, relu)
+
+    def conv_dgrad(self, dy, W, dx, B, H, Wd, Cin, Cout, k, acc=0):
+        """dx[B,H,W,Cin] (+)= conv^T(dy[B,H,W,Cout]);  W is the forward OIHW weight [Cout,Cin,k,k]."""
+        T = k * k
+        self.L.conv_fwd(dy, W, None, dx, B, H, Wd, Cout, Cin, k, k, Cout, Cin, T, Cin * T, T - 1, -1, acc, 0)
+
+    def conv_wgrad(self, x, dy, dW, db, B, H, Wd, Cin, Cout, k):
+        T = k * k
+        tiles = (-(-Cout // 128) * -(-(T * Cin) // 64)) if Cout > 16 else (-(-(T * Cin) // 128))
+        sk = max(1, min((B * H * Wd) // 256, -(-1024 // tiles)))
+        while sk > 1 and Cout * T * Cin * sk > WS_FLOATS:
+            sk //= 2
+        self.L.conv_wgrad(x, dy, dW, B, H, Wd, Cin, Cout, k, k, Cin, Cout, sk, self.ws, 1)
+        self.colsum(dy, B * H * Wd, Cout, db)
+
+    def bn(self, pre, x, R, C, train, act, out=None, res=None):
+        P = self.P
+        stat = self.new(2, C)
+        if train:
+            self.L.bn_stats(x, C, R, C, 1e-5, 0.1, stat, P[pre + "running_mean"], P[pre + "running_var"], self.ws)
+            P[pre + "num_batches_tracked"] += 1
+        else:
+            self.L.bn_stat_from_running(P[pre + "running_mean"], P[pre + "running_var"], C, 1e-5, stat)
+        y = out if out is not None else self.new(R, C)
+        self.L.bn_apply(x, C, stat, P[pre + "weight"], P[pre + "bias"], res, C, y, C, R, C, act)
+        return y, stat
+
+    def bn_bwd(self, pre, x, dy, stat, R, C, act, train, G):
+        dx = self.new(R, C)
+        self.L.bn_bwd(x, C, dy, C, stat, self.P[pre + "weight"], self.P[pre + "bias"], dx, C, G[pre + "weight"],
+                      G[pre + "bias"], R, C, act, 1 if train else 0, 1, 0, self.ws)
+        return dx
+
+    def dropcfg(self, site, seed, p):
+        if p <= 0.0:
+            return NODROP
+        ss = (seed * 0x85EBCA77 + DROP_SITES[site] * 0xC2B2AE3D) & 0xFFFFFFFF
+        return (ss, int(p * (1 << 24)), 1.0 / (1.0 - p))
+
+    # ---- GRU block (1x1 conv + BiGRU) ------------------------------------------------------------------------
+    def _seqmap(self, B, H, W, vertical):
+        # (nseq, T, inner, outer_stride, inner_stride, tstride) in pixels of the NHWC [B,H,W,*] buffer
+        if vertical:
+            return (B * W, H, W, H * W, 1, W)
+        return (B * H, W, 1, W, 0, 1)
+
+    def gru_block_fwd(self, pre, inputs, B, H, W, vertical, save, ctx, key):
+        """inputs: list of (x[R,Kc], column offset in conv1.weight, Kc).  Returns out [R,64]."""
+        P, R = self.P, B * H * W
+        Wc = P[pre + "conv1.weight"]
+        Ktot = Wc.shape[1]
+        g_in = self.new(R, 64)
+        for i, (x, off, kc) in enumerate(inputs):
+            self.linear(x, Wc.view(-1)[off:], P[pre + "conv1.bias"] if i == 0 else None, g_in, R, 64, kc, ldw=Ktot, acc=int(i > 0))
+        gi = self.new(R, 192)
+        self.linear(g_in, P[pre + "gru.weight_ih_l0"], P[pre + "gru.bias_ih_l0"], gi, R, 96, 64, ldc=192)
+        self.linear(g_in, P[pre + "gru.weight_ih_l0_reverse"], P[pre + "gru.bias_ih_l0_reverse"], gi.view(-1)[96:], R, 96, 64, ldc=192)
+        out = self.new(R, 64)
+        sv = self.new(R, 2, 4, 32) if save else None
+        self.L.gru32_fwd(gi, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], P[pre + "gru.bias_hh_l0"],
+                         P[pre + "gru.bias_hh_l0_reverse"], out, sv, *self._seqmap(B, H, W, vertical))
+        if save:
+            ctx[key] = (g_in, out, sv)
+        return out
+
+    def gru_block_bwd(self, pre, dout, inputs, B, H, W, vertical, ctx, key, G):
+        """inputs: list of (x, off, kc, dx or None, acc).  Writes parameter grads, input grads into dx."""
+        P, R = self.P, B * H * W
+        g_in, out, sv = ctx[key]
+        dgi, dgh, hprev = self.new(R, 192), self.new(R, 192), self.new(R, 64)
+        self.L.gru32_bwd(dout, out, sv, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], dgi, dgh, hprev,
+                         *self._seqmap(B, H, W, vertical))
+        dg_in = self.new(R, 64)
+        for d, sfx in enumerate(["", "_reverse"]):
+            gi_d, gh_d, hp_d = dgi.view(-1)[96 * d:], dgh.view(-1)[96 * d:], hprev.view(-1)[32 * d:]
+            self.linear_dw(gh_d, hp_d, G[pre + "gru.weight_hh_l0" + sfx], R, 96, 32, lddy=192, ldx=64)
+            self.colsum(gh_d, R, 96, G[pre + "gru.bias_hh_l0" + sfx], ld=192)
+            self.linear_dw(gi_d, g_in, G[pre + "gru.weight_ih_l0" + sfx], R, 96, 64, lddy=192)
+            self.colsum(gi_d, R, 96, G[pre + "gru.bias_ih_l0" + sfx], ld=192)
+            self.linear_dx(gi_d, P[pre + "gru.weight_ih_l0" + sfx], dg_in, R, 96, 64, lddy=192, acc=d)
+        Wc, dWc = P[pre + "conv1.weight"], G[pre + "conv1.weight"]
+        Ktot = Wc.shape[1]
+        self.colsum(dg_in, R, 64, G[pre + "conv1.bias"])
+        for (x, off, kc, dx, acc) in inputs:
+            self.linear_dw(dg_in, x, dWc.view(-1)[off:], R, 64, kc, lddw=Ktot)
+            if dx is not None:
+                self.linear_dx(dg_in, Wc.view(-1)[off:], dx, R, 64, kc, ldw=Ktot, acc=acc)
+
+    # ---- attention block pieces ------------------------------------------------------------------------------------
+    def mha_fwd(self, pre, q_in, k_in, v_in, B, Lq, cfg):
+        P = self.P
+        W, b = P[pre + "in_proj_weight"], P[pre + "in_proj_bias"]
+        Rq, Rk = B * Lq, B * 26
+        Q, K, V = self.new(Rq, 64), self.new(Rk, 64), self.new(Rk, 64)
+        self.linear(q_in, W, b, Q, Rq, 64, 64)
+        self.linear(k_in, W[64:], b[64:], K, Rk, 64, 64)
+        self.linear(v_in, W[128:], b[128:], V, Rk, 64, 64)
+        c = self.new(Rq, 64)
+        self.L.attn_fwd(Q, K, V, c, None, B, Lq, 26, *cfg)
+        a = self.new(Rq, 64)
+        self.linear(c, P[pre + "out_proj.weight"], P[pre + "out_proj.bias"], a, Rq, 64, 64)
+        return a, (Q, K, V, c)
+
+    def mha_bwd(self, pre, da, saved, q_in, k_in, v_in, B, Lq, cfg, G, dq_in, dk_in, dv_in, acc_q, acc_k, acc_v):
+        """da [Rq,64] -> grads of projections; input grads (+)= into dq_in/dk_in/dv_in."""
+        P = self.P
+        Q, K, V, c = saved
+        Rq, Rk = B * Lq, B * 26
+        W = P[pre + "in_proj_weight"]
+        dW, db = G[pre + "in_proj_weight"], G[pre + "in_proj_bias"]
+        self.linear_dw(da, c, G[pre + "out_proj.weight"], Rq, 64, 64)
+        self.colsum(da, Rq, 64, G[pre + "out_proj.bias"])
+        dc = self.new(Rq, 64)
+        self.linear_dx(da, P[pre + "out_proj.weight"], dc, Rq, 64, 64)
+        dQ, dK, dV = self.new(Rq, 64), self.new(Rk, 64), self.new(Rk, 64)
+        self.L.attn_bwd(Q, K, V, dc, dQ, dK, dV, B, Lq, 26, *cfg, 0)
+        for i, (d, x, R, dx, acc) in enumerate([(dQ, q_in, Rq, dq_in, acc_q), (dK, k_in, Rk, dk_in, acc_k), (dV, v_in, Rk, dv_in, acc_v)]):
+            self.linear_dw(d, x, dW[64 * i:], R, 64, 64)
+            self.colsum(d, R, 64, db[64 * i:])
+            if dx is not None:
+                self.linear_dx(d, W[64 * i:], dx, R, 64, 64, acc=acc)
+
+    def ffn_fwd(self, pre, x, R, cfg):
+        P = self.P
+        h = self.new(R, 64)
+        self.linear(x, P[pre + "linear1.weight"], P[pre + "linear1.bias"], h, R, 64, 64, relu=1)
+        hd = h
+        if cfg[1]:
+            hd = self.new(R, 64)
+            self.L.dropout_mul(h, hd, R * 64, *cfg)
+        f = self.new(R, 64)
+        self.linear(hd, P[pre + "linear2.weight"], P[pre + "linear2.bias"], f, R, 64, 64)
+        return f, (h, hd)
+
+    def ffn_bwd(self, pre, df, saved, x, R, cfg, G, dx):
+        """dx += d/dx of linear2(drop(relu(linear1 x)))"""
+        P = self.P
+        h, hd = saved
+        self.linear_dw(df, hd, G[pre + "linear2.weight"], R, 64, 64)
+        self.colsum(df, R, 64, G[pre + "linear2.bias"])
+        dh = self.new(R, 64)
+        self.linear_dx(df, P[pre + "linear2.weight"], dh, R, 64, 64)
+        self.L.relu_drop_bwd(h, dh, dh, R * 64, *cfg)
+        self.linear_dw(dh, x, G[pre + "linear1.weight"], R, 64, 64)
+        self.colsum(dh, R, 64, G[pre + "linear1.bias"])
+        self.linear_dx(dh, P[pre + "linear1.weight"], dx, R, 64, 64, acc=1)
+
+    def ln_fwd(self, pre, x, res, cfg, R, save_v=True):
+        v = self.new(R, 64) if (res is not None and save_v) else None
+        y = self.new(R, 64)
+        self.L.ln_fwd(x, res, *cfg, self.P[pre + "weight"], self.P[pre + "bias"], v, y, R, 1e-5)
+        return y, (v if v is not None else x)
+
+    def ln_bwd(self, pre, v, dy, dyscale, dv, dv_acc, cfg, R, G, want_dres):
+        """dv (+)= grad wrt the LN input v;  returns dres (grad wrt the dropped residual branch)."""
+        dres = self.new(R, 64) if (want_dres and cfg[1]) else None
+        self.L.ln_bwd(v, dy, dyscale, self.P[pre + "weight"], dv, dv_acc, dres, *cfg, G[pre + "weight"], G[pre + "bias"], 1, R,
+                      1e-5, self.ws)
+        return dres
+
+    # ================================================================================================================
+    def forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True):
+        L, m = self.L, self.m
+        self.refresh()
+        P = self.P
+        B, C, H, W = x.shape
+        if (C, H, W) != (4, 16, 64):
+            raise RuntimeError(f"expected LR input [B,4,16,64], got {tuple(x.shape)}")
+        K = m.text_embedding
+        if tuple(text_emb.shape) != (B, K, 1, 26):
+            raise RuntimeError(f"expected text prior [B,{K},1,26], got {tuple(text_emb.shape)}")
+        x = x.detach().contiguous().float()
+        text_emb = text_emb.detach().float()
+        p = (m.dropout_p if p_drop is None else p_drop) if training else 0.0
+        cfg = lambda site: self.dropcfg(site, seed, p)
+        ctx = Ctx()
+        ctx["meta"] = (B, training, seed, p)
+        R0 = B * H * W
+        use_stn = bool(m.stn and training)
+        ctx["x"] = x
+
+        # ---- STN head + TPS rectification (model/tsrn.py:655-657) ------------------------------------------
+        if use_stn:
+            xn = self.new(R0, 4)
+            L.nchw_to_nhwc(x, xn, B, 4, H * W)
+            h, hh, ww = xn, H, W
+            stn_saved = []
+            for (idx, cin, cout, pool) in STN_STAGES:
+                pre = f"stn_head.stn_convnet.{idx}."
+                Rr = B * hh * ww
+                c = self.new(Rr, cout)
+                self.conv(h, P[pre + "0.weight"], P[pre + "0.bias"], c, B, hh, ww, cin, cout, 3)
+                a, stat = self.bn(pre + "1.", c, Rr, cout, True, 1)
+                rec = [h, c, stat, a, hh, ww]
+                if pool is not None:
+                    hp = self.new(B * (hh // pool[0]) * (ww // pool[1]), cout)
+                    L.maxpool_fwd(a, hp, B, hh, ww, cout, pool[0], pool[1])
+                    h, hh, ww = hp, hh // pool[0], ww // pool[1]
+                else:
+                    h = a
+                stn_saved.append(rec)
+            f = self.new(B, 512)
+            L.nhwc_to_nchw(h, f, B, 256, 2)                                   # flatten order of x.view(B,-1) on NCHW
+            l1 = self.new(B, 512)
+            self.linear(f, P["stn_head.stn_fc1.0.weight"], P["stn_head.stn_fc1.0.bias"], l1, B, 512, 512)
+            feat, stat1 = self.bn("stn_head.stn_fc1.1.", l1, B, 512, True, 1)
+            feat01 = self.new(B, 512)
+            L.axpby(feat, 0.1, None, 0.0, feat01, B * 512, 0)
+            ctrl = self.new(B, 40)
+            self.linear(feat01, P["stn_head.stn_fc2.weight"], P["stn_head.stn_fc2.bias"], ctrl, B, 40, 512)
+            Tm = self.new(H * W, 20)                                          # target_coordinate_repr @ inverse_kernel[:, :20]
+            L.gemm(P["tps.target_coordinate_repr"], P["tps.inverse_kernel"], Tm, None, H * W, 20, 23, 23, 1, 1, 23, 20,
+                   1, 0, 0, 0, 0, 0, 1, None)
+            xs = self.new(R0, 4)
+            L.tps_sample_fwd(x, ctrl, Tm, xs, None, B, 4, H, W)
+            ctx["stn"] = (stn_saved, f, l1, stat1, feat01, ctrl, Tm)
+        else:
+            xs = self.new(R0, 4)
+            L.nchw_to_nhwc(x, xs, B, 4, H * W)
+        ctx["xs"] = xs
+
+        # ---- block1: conv9x9 + PReLU -----------------------------------------------------------------------------
+        c1 = self.new(R0, 64)
+        self.conv(xs, P["block1.0.weight"], P["block1.0.bias"], c1, B, H, W, 4, 64, 9)
+        b1 = self.new(R0, 64)
+        L.prelu_fwd(c1, P["block1.1.weight"], b1, R0 * 64)
+        ctx["c1"], ctx["b1"] = c1, b1
+
+        # ---- TP interpreter (model/tsrn.py:194-226, model/transformer_v2.py:198-244) -----------------------------------
+        ig, tr = "infoGen.", "infoGen.transformer."
+        Rt = B * 26
+        tpr = self.new(Rt, K)
+        L.tp_rows(text_emb, text_emb.stride(0), text_emb.stride(1), text_emb.stride(3), tpr, B, K, 26)
+        t0 = self.new(Rt, 64)
+        self.linear(tpr, P[ig + "fc_in.weight"], P[ig + "fc_in.bias"], t0, Rt, 64, K)
+        t = self.new(Rt, 64)
+        L.prelu_fwd(t0, P[ig + "activation.weight"], t, Rt * 64)
+        pos = self.new(Rt, 64)
+        L.pe_dropout(P[ig + "pe.pe"], pos, B, 26, *cfg("pe"))
+        # recurrent positional encoding: GRU over the batch axis, identical input at every step
+        g = tr + "gru_encoding."
+        xg = self.new(64, 1024)
+        L.rpe_gather_x(P[ig + "init_factor.weight"], xg)
+        gi = self.new(2, 64, 1536)
+        self.linear(xg, P[g + "weight_ih_l0"], P[g + "bias_ih_l0"], gi[0], 64, 1536, 1024)
+        self.linear(xg, P[g + "weight_ih_l0_reverse"], P[g + "bias_ih_l0_reverse"], gi[1], 64, 1536, 1024)
+        hstep = self.zeros(2, B + 1, 64, 512)
+        gh_all = self.new(2, B, 64, 1536)
+        qp = self.new(R0, 64)
+        whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
+        wdiff = (whh_b.data_ptr() - whh_f.data_ptr()) // 4
+        dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
+        for s in range(B):
+            L.gemm(hstep[0, s], whh_f, gh_all[0, s], None, 64, 1536, 512, 512, 1, 512, 1, 1536, 2, dsh, wdiff, dsg, 0, 0, 1, None)
+            L.rpe_gate_fwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], hstep[0, s + 1], qp,
+                           s, B, dsg, dsh)
+        # encoder layer (input doubled, model/transformer_v2.py:273)
+        e = tr + "encoder.layers.0."
+        src2, qk = self.new(Rt, 64), self.new(Rt, 64)
+        L.axpby(t, 2.0, None, 0.0, src2, Rt * 64, 0)
+        L.axpby(src2, 1.0, pos, 1.0, qk, Rt * 64, 0)
+        a_e, att_e = self.mha_fwd(e + "self_attn.", qk, qk, src2, B, 26, cfg("enc_attn"))
+        s1, v1e = self.ln_fwd(e + "norm1.", src2, a_e, cfg("enc_drop1"), Rt)
+        f_e, ffn_e = self.ffn_fwd(e, s1, Rt, cfg("enc_ffn"))
+        mem, v2e = self.ln_fwd(e + "norm2.", s1, f_e, cfg("enc_drop2"), Rt)
+        kin = self.new(Rt, 64)
+        L.axpby(mem, 1.0, pos, 1.0, kin, Rt * 64, 0)
+        # decoder layers (cross attention only, model/transformer_v2.py:805-832)
+        tgt = b1
+        dec = []
+        tp_map = self.new(R0, 64)
+        for li in range(2):
+            d = f"{tr}decoder.layers.{li}."
+            qin = self.new(R0, 64)
+            L.axpby(tgt, 1.0, qp, 1.0, qin, R0 * 64, 0)
+            a, att = self.mha_fwd(d + "multihead_attn.", qin, kin, mem, B, H * W, cfg(f"dec{li}_attn"))
+            t2, v2 = self.ln_fwd(d + "norm2.", tgt, a, cfg(f"dec{li}_drop2"), R0)
+            f_, ffn = self.ffn_fwd(d, t2, R0, cfg(f"dec{li}_ffn"))
+            t3, v3 = self.ln_fwd(d + "norm3.", t2, f_, cfg(f"dec{li}_drop3"), R0)
+            inter, _ = self.ln_fwd(tr + "decoder.norm.", t3, None, NODROP, R0)
+            L.axpby(inter, 0.5, None, 0.0, tp_map, R0 * 64, int(li > 0))
+            dec.append((tgt, qin, att, v2, t2, ffn, v3, t3))
+            tgt = t3
+        ctx["tp"] = (tpr, t0, t, pos, xg, gi, hstep, gh_all, qp, src2, qk, att_e, v1e, s1, ffn_e, v2e, mem, kin, dec)
+        ctx["tp_map"] = tp_map
+
+        # ---- SRBs (model/tsrn.py:883-901) ----------------------------------------------------------------------------
+        blk = b1
+        srbs = []
+        for i in range(m.srb_nums):
+            pre = f"block{i + 2}."
+            ca = self.new(R0, 64)
+            self.conv(blk, P[pre + "conv1.weight"], P[pre + "conv1.bias"], ca, B, H, W, 64, 64, 3)
+            ma, st1 = self.bn(pre + "bn1.", ca, R0, 64, training, 2)
+            cb = self.new(R0, 64)
+            self.conv(ma, P[pre + "conv2.weight"], P[pre + "conv2.bias"], cb, B, H, W, 64, 64, 3)
+            r2, st2 = self.bn(pre + "bn2.", cb, R0, 64, training, 0)
+            r = self.gru_block_fwd(pre + "gru1.", [(r2, 0, 64), (tp_map, 64, 64)], B, H, W, True, want_ctx, ctx, pre + "gru1")
+            s = self.new(R0, 64)
+            L.axpby(blk, 1.0, r, 1.0, s, R0 * 64, 0)
+            out = self.gru_block_fwd(pre + "gru2.", [(s, 0, 64)], B, H, W, False, want_ctx, ctx, pre + "gru2")
+            srbs.append((blk, ca, st1, ma, cb, st2, r2, s))
+            blk = out
+        ctx["srbs"] = srbs
+
+        # ---- block7 (conv+BN) + global residual, block8 (upsample + 9x9) + sigmoid ---------------------------------------
+        k7 = f"block{m.srb_nums + 2}."
+        c7 = self.new(R0, 64)
+        self.conv(blk, P[k7 + "0.weight"], P[k7 + "0.bias"], c7, B, H, W, 64, 64, 3)
+        u_in, st7 = self.bn(k7 + "1.", c7, R0, 64, training, 0, res=b1)
+        k8 = f"block{m.srb_nums + 3}."
+        cu = self.new(R0, 256)
+        self.conv(u_in, P[k8 + "0.conv.weight"], P[k8 + "0.conv.bias"], cu, B, H, W, 64, 256, 3)
+        up = self.new(4 * R0, 64)
+        L.pixshuf_mish_fwd(cu, up, B, H, W, 64)
+        pre_s = self.new(4 * R0, 4)
+        self.conv(up, P[k8 + "1.weight"], P[k8 + "1.bias"], pre_s, B, 2 * H, 2 * W, 64, 4, 9)
+        sr = self.new(B, 4, 2 * H, 2 * W)
+        L.sigmoid_to_nchw(pre_s, sr, B, 4, 4 * H * W)
+        ctx["tail"] = (blk, c7, st7, u_in, cu, up, pre_s)
+        ctx["sr"] = sr
+        ctx["use_stn"] = use_stn
+        return sr, ctx
+
+    # ================================================================================================================
+    def backward(self, ctx, dsr, G):
+        """Accumulates parameter gradients of one forward call into G (dict name -> fp32 tensor)."""
+        L, m, P = self.L, self.m, self.P
+        B, training, seed, p = ctx["meta"]
+        cfg = lambda site: self.dropcfg(site, seed, p)
+        H, W = 16, 64
+        R0 = B * H * W
+        dsr = dsr.contiguous().float()
+        blk_last, c7, st7, u_in, cu, up, pre_s = ctx["tail"]
+        b1, c1, tp_map = ctx["b1"], ctx["c1"], ctx["tp_map"]
+        k7, k8 = f"block{m.srb_nums + 2}.", f"block{m.srb_nums + 3}."
+
+        # ---- tail ------------------------------------------------------------------------------------------------
+        dpre = self.new(4 * R0, 4)
+        L.sigmoid_bwd_to_nhwc(ctx["sr"], dsr, dpre, B, 4, 4 * H * W)
+        self.conv_wgrad(up, dpre, G[k8 + "1.weight"], G[k8 + "1.bias"], B, 2 * H, 2 * W, 64, 4, 9)
+        dup = self.new(4 * R0, 64)
+        self.conv_dgrad(dpre, P[k8 + "1.weight"], dup, B, 2 * H, 2 * W, 64, 4, 9)
+        dcu = self.new(R0, 256)
+        L.pixshuf_mish_bwd(cu, dup, dcu, B, H, W, 64)
+        self.conv_wgrad(u_in, dcu, G[k8 + "0.conv.weight"], G[k8 + "0.conv.bias"], B, H, W, 64, 256, 3)
+        db1 = self.new(R0, 64)                                               # grad of block1 output, accumulated below
+        self.conv_dgrad(dcu, P[k8 + "0.conv.weight"], db1, B, H, W, 64, 256, 3)
+        dc7 = self.bn_bwd(k7 + "1.", c7, db1, st7, R0, 64, 0, training, G)
+        self.conv_wgrad(blk_last, dc7, G[k7 + "0.weight"], G[k7 + "0.bias"], B, H, W, 64, 64, 3)
+        dout = self.new(R0, 64)
+        self.conv_dgrad(dc7, P[k7 + "0.weight"], dout, B, H, W, 64, 64, 3)
+
+        # ---- SRBs, last to first ----------------------------------------------------------------------------------
+        dtp = self.new(R0, 64)
+        first_tp = True
+        for i in reversed(range(m.srb_nums)):
+            pre = f"block{i + 2}."
+            blk, ca, st1, ma, cb, st2, r2, s = ctx["srbs"][i]
+            ds = self.new(R0, 64)
+            self.gru_block_bwd(pre + "gru2.", dout, [(s, 0, 64, ds, 0)], B, H, W, False, ctx, pre + "gru2", G)
+            dr2 = self.new(R0, 64)
+            self.gru_block_bwd(pre + "gru1.", ds, [(r2, 0, 64, dr2, 0), (tp_map, 64, 64, dtp, 0 if first_tp else 1)], B, H, W,
+                               True, ctx, pre + "gru1", G)
+            first_tp = False
+            dcb = self.bn_bwd(pre + "bn2.", cb, dr2, st2, R0, 64, 0, training, G)
+            self.conv_wgrad(ma, dcb, G[pre + "conv2.weight"], G[pre + "conv2.bias"], B, H, W, 64, 64, 3)
+            dma = self.new(R0, 64)
+            self.conv_dgrad(dcb, P[pre + "conv2.weight"], dma, B, H, W, 64, 64, 3)
+            dca = self.bn_bwd(pre + "bn1.", ca, dma, st1, R0, 64, 2, training, G)
+            self.conv_wgrad(blk, dca, G[pre + "conv1.weight"], G[pre + "conv1.bias"], B, H, W, 64, 64, 3)
+            self.conv_dgrad(dca, P[pre + "conv1.weight"], ds, B, H, W, 64, 64, 3, acc=1)     # dx = ds + conv1^T(dca)
+            dout = ds
+        L.axpby(dout, 1.0, None, 0.0, db1, R0 * 64, 1)
+
+        # ---- TP interpreter --------------------------------------------------------------------------------------
+        ig, tr = "infoGen.", "infoGen.transformer."
+        (tpr, t0, t, pos, xg, gi, hstep, gh_all, qp, src2, qk, att_e, v1e, s1, ffn_e, v2e, mem, kin, dec) = ctx["tp"]
+        Rt, K = B * 26, m.text_embedding
+        dqp = self.new(R0, 64)
+        dmem, dkin = self.new(Rt, 64), self.new(Rt, 64)
+        dnext = None                                                           # grad flowing into layer li's output from above
+        for li in (1, 0):
+            d = f"{tr}decoder.layers.{li}."
+            tgt, qin, att, v2, t2, ffn, v3, t3 = dec[li]
+            dt3 = self.new(R0, 64) if dnext is None else dnext
+            self.ln_bwd(tr + "decoder.norm.", t3, dtp, 0.5, dt3, 0 if dnext is None else 1, NODROP, R0, G, False)
+            dt2 = self.new(R0, 64)
+            df = self.ln_bwd(d + "norm3.", v3, dt3, 1.0, dt2, 0, cfg(f"dec{li}_drop3"), R0, G, True)
+            self.ffn_bwd(d, df if df is not None else dt2, ffn, t2, R0, cfg(f"dec{li}_ffn"), G, dt2)
+            dtgt = self.new(R0, 64)
+            da = self.ln_bwd(d + "norm2.", v2, dt2, 1.0, dtgt, 0, cfg(f"dec{li}_drop2"), R0, G, True)
+            dqin = self.new(R0, 64)
+            last = li == 1
+            self.mha_bwd(d + "multihead_attn.", da if da is not None else dtgt, att, qin, kin, mem, B, H * W,
+                         cfg(f"dec{li}_attn"), G, dqin, dkin, dmem, 0, 0 if last else 1, 0 if last else 1)
+            L.axpby(dqin, 1.0, None, 0.0, dtgt, R0 * 64, 1)
+            L.axpby(dqin, 1.0, None, 0.0, dqp, R0 * 64, 0 if last else 1)
+            dnext = dtgt
+        L.axpby(dnext, 1.0, None, 0.0, db1, R0 * 64, 1)
+        L.axpby(dkin, 1.0, None, 0.0, dmem, Rt * 64, 1)                     # kin = mem + pos
+        # encoder
+        e = tr + "encoder.layers.0."
+        ds1 = self.new(Rt, 64)
+        dfe = self.ln_bwd(e + "norm2.", v2e, dmem, 1.0, ds1, 0, cfg("enc_drop2"), Rt, G, True)
+        self.ffn_bwd(e, dfe if dfe is not None else ds1, ffn_e, s1, Rt, cfg("enc_ffn"), G, ds1)
+        dsrc2 = self.new(Rt, 64)
+        dae = self.ln_bwd(e + "norm1.", v1e, ds1, 1.0, dsrc2, 0, cfg("enc_drop1"), Rt, G, True)
+        dqk = self.new(Rt, 64)
+        self.mha_bwd(e + "self_attn.", dae if dae is not None else dsrc2, att_e, qk, qk, src2, B, 26, cfg("enc_attn"), G,
+                     dqk, dqk, dsrc2, 0, 1, 1)
+        L.axpby(dqk, 1.0, None, 0.0, dsrc2, Rt * 64, 1)
+        dt = self.new(Rt, 64)
+        L.axpby(dsrc2, 2.0, None, 0.0, dt, Rt * 64, 0)
+        dt0 = self.new(Rt, 64)
+        L.prelu_bwd(t0, P[ig + "activation.weight"], dt, dt0, G[ig + "activation.weight"], 1, Rt * 64, self.ws)
+        self.linear_dw(dt0, tpr, G[ig + "fc_in.weight"], Rt, 64, K)
+        self.colsum(dt0, Rt, 64, G[ig + "fc_in.bias"])
+        # recurrent positional encoding, BPTT over the batch axis
+        g = tr + "gru_encoding."
+        whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
+        wdiff = (whh_b.data_ptr() - whh_f.data_ptr()) // 4
+        dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
+        carry = self.zeros(2, 64, 512)
+        dgi_sum = self.zeros(2, 64, 1536)
+        dgh_all = self.new(2, B, 64, 1536)
+        for s in reversed(range(B)):
+            L.rpe_gate_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
+                           dgh_all[0, s], dgi_sum, s, B, dsg, dsh)
+            if s > 0:
+                L.gemm(dgh_all[0, s], whh_f, carry, None, 64, 512, 1536, 1536, 1, 1, 512, 512, 2, dsg, wdiff, 64 * 512, 1, 0, 1, None)
+        dxg = self.new(64, 1024)
+        for dd, sfx in enumerate(["", "_reverse"]):
+            self.linear_dw(dgh_all[dd], hstep[dd], G[g + "weight_hh_l0" + sfx], 64 * B, 1536, 512)
+            self.colsum(dgh_all[dd], 64 * B, 1536, G[g + "bias_hh_l0" + sfx])
+            self.linear_dw(dgi_sum[dd], xg, G[g + "weight_ih_l0" + sfx], 64, 1536, 1024)
+            self.colsum(dgi_sum[dd], 64, 1536, G[g + "bias_ih_l0" + sfx])
+            self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd)
+        L.rpe_scatter_dx(dxg, G[ig + "init_factor.weight"], 1)
+
+        # ---- block1 ------------------------------------------------------------------------------------------------
+        dc1 = self.new(R0, 64)
+        L.prelu_bwd(c1, P["block1.1.weight"], db1, dc1, G["block1.1.weight"], 1, R0 * 64, self.ws)
+        xs = ctx["xs"]
+        self.conv_wgrad(xs, dc1, G["block1.0.weight"], G["block1.0.bias"], B, H, W, 4, 64, 9)
+        if not ctx["use_stn"]:
+            return
+        # ---- TPS + STN head ----------------------------------------------------------------------------------------
+        stn_saved, f, l1, stat1, feat01, ctrl, Tm = ctx["stn"]
+        dxs = self.new(R0, 4)
+        self.conv_dgrad(dc1, P["block1.0.weight"], dxs, B, H, W, 4, 64, 9)
+        dctrl = self.new(B, 40)
+        L.tps_sample_bwd(ctx["x"], ctrl, Tm, dxs, dctrl, B, 4, H, W, 0)
+        self.linear_dw(dctrl, feat01, G["stn_head.stn_fc2.weight"], B, 40, 512)
+        self.colsum(dctrl, B, 40, G["stn_head.stn_fc2.bias"])
+        dfeat = self.new(B, 512)
+        self.linear_dx(dctrl, P["stn_head.stn_fc2.weight"], dfeat, B, 40, 512)
+        L.axpby(dfeat, 0.1, None, 0.0, dfeat, B * 512, 0)
+        dl1 = self.bn_bwd("stn_head.stn_fc1.1.", l1, dfeat, stat1, B, 512, 1, True, G)
+        self.linear_dw(dl1, f, G["stn_head.stn_fc1.0.weight"], B, 512, 512)
+        self.colsum(dl1, B, 512, G["stn_head.stn_fc1.0.bias"])
+        df = self.new(B, 512)
+        self.linear_dx(dl1, P["stn_head.stn_fc1.0.weight"], df, B, 512, 512)
+        dh = self.new(B * 2, 256)
+        L.nchw_to_nhwc(df, dh, B, 256, 2)
+        for (idx, cin, cout, pool), rec in zip(reversed(STN_STAGES), reversed(stn_saved)):
+            pre = f"stn_head.stn_convnet.{idx}."
+            hin, c, stat, a, hh, ww = rec
+            Rr = B * hh * ww
+            if pool is not None:
+                da = self.new(Rr, cout)
+                L.maxpool_bwd(a, dh, da, B, hh, ww, cout, pool[0], pool[1])
+            else:
+                da = dh
+            dc = self.bn_bwd(pre + "1.", c, da, stat, Rr, cout, 1, True, G)
+            self.conv_wgrad(hin, dc, G[pre + "0.weight"], G[pre + "0.bias"], B, hh, ww, cin, cout, 3)
+            if idx > 0:
+                dh = self.new(Rr, cin)
+                self.conv_dgrad(dc, P[pre + "0.weight"], dh, B, hh, ww, cin, cout, 3)
+
+
+# parameters that never receive a gradient in the reference: autograd must see None for them
+def unused_param(name: str) -> bool:
+    return (name.startswith("infoGen.fc_feature_in.") or
+            (".decoder.layers." in name and (".self_attn." in name or ".norm1." in name)))
+
+
+class TSRNFunction(torch.autograd.Function):
+    """Autograd boundary of the module: one node for the whole network."""
+
+    @staticmethod
+    def forward(fctx, eng, x, text_emb, training, seed, *params):
+        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        sr, ctx = eng.forward(x, text_emb, training, seed, want_ctx=True)
+        fctx.eng, fctx.c, fctx.need = eng, ctx if need else None, need
+        fctx.names = eng._names
+        fctx.req = [p.requires_grad for p in params]
+        return sr
+
+    @staticmethod
+    def backward(fctx, dsr):
+        eng = fctx.eng
+        if fctx.c is None:
+            raise RuntimeError("backward through a forward that saved no context")
+        shapes = {n: eng.P[n].shape for n in fctx.names}
+        total = sum(s.numel() for s in shapes.values())
+        flat = torch.zeros(total, device=dsr.device, dtype=torch.float32)
+        G, off = {}, 0
+        for n in fctx.names:
+            k = shapes[n].numel()
+            G[n] = flat[off:off + k].view(shapes[n])
+            off += k
+        eng.backward(fctx.c, dsr, G)
+        grads = [G[n] if (req and not unused_param(n)) else None for n, req in zip(fctx.names, fctx.req)]
+        return (None, None, None, None, None, *grads)

@@ -1,0 +1,138 @@
+"""TSRN_TL_TRANS — the TATT super-resolution generator, MI355X-native.
+
+Drop-in for the reference class of the same name (model/tsrn.py:577-684): same constructor signature, same
+``forward(x, text_emb=None) -> Tensor[B,4,2H,2W]`` contract, same ``state_dict`` keys/shapes,
+same ``train()/eval()`` semantics (STN only in training, BN batch/running stats, dropout).  The sub-modules
+below are parameter containers with the reference's names; all arithmetic runs in hand-written HIP kernels
+driven by ``tatt_amd.engine`` through the C-ABI in ``include/tatt_hip.h``.  There is no non-HIP fallback.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .stn_head import STNHead
+from .tps_spatial_transformer import TPSSpatialTransformer
+from .transformer_v2 import InfoTransformer, PositionalEncoding
+
+
+class mish(nn.Module):
+    """x*tanh(softplus(x)) marker module (model/tsrn.py:1064-1072); fused into the BN / pixel-shuffle kernels."""
+
+    def __init__(self):
+        super().__init__()
+        self.activated = True
+
+
+class GruBlock(nn.Module):
+    """1x1 conv + BiGRU(out -> 2 x out/2) over the last spatial axis (model/tsrn.py:1075-1092)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        assert out_channels % 2 == 0
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=1, padding=0)
+        self.gru = nn.GRU(out_channels, out_channels // 2, bidirectional=True, batch_first=True)
+
+
+class RecurrentResidualBlockTL(nn.Module):
+    """SRB with text-prior fusion (model/tsrn.py:865-901)."""
+
+    def __init__(self, channels, text_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
+        self.bn1 = nn.BatchNorm2d(channels)
+        self.gru1 = GruBlock(channels + text_channels, channels)
+        self.prelu = mish()
+        self.conv2 = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
+        self.bn2 = nn.BatchNorm2d(channels)
+        self.gru2 = GruBlock(channels, channels)
+
+
+class UpsampleBLock(nn.Module):
+    """conv3x3 (C -> C*s^2) + PixelShuffle + mish (model/tsrn.py:1031-1044)."""
+
+    def __init__(self, in_channels, up_scale):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels * up_scale ** 2, kernel_size=3, padding=1)
+        self.pixel_shuffle = nn.PixelShuffle(up_scale)
+        self.prelu = mish()
+
+
+class TPInterpreter(nn.Module):
+    """Text-prior interpreter (model/tsrn.py:155-226)."""
+
+    def __init__(self, text_embedding, out_text_channels, output_size=(16, 64), feature_in=64, t_encoder_num=1,
+                 t_decoder_num=2):
+        super().__init__()
+        d_model = out_text_channels
+        self.fc_in = nn.Linear(text_embedding, d_model)
+        self.fc_feature_in = nn.Linear(feature_in, d_model)     # constructed, never used by forward (no gradient)
+        self.activation = nn.PReLU()
+        self.transformer = InfoTransformer(d_model=d_model, dropout=0.1, nhead=4, dim_feedforward=d_model,
+                                           num_encoder_layers=t_encoder_num, num_decoder_layers=t_decoder_num,
+                                           normalize_before=False, return_intermediate_dec=True,
+                                           feat_height=output_size[0], feat_width=output_size[1])
+        self.pe = PositionalEncoding(d_model=d_model, dropout=0.1, max_len=5000)
+        self.output_size = output_size
+        self.seq_len = output_size[1] * output_size[0]
+        self.init_factor = nn.Embedding(self.seq_len, d_model)
+        self.masking = torch.ones(output_size)
+
+
+class TSRN_TL_TRANS(nn.Module):
+    def __init__(self, scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32,
+                 word_vec_d=300, text_embedding=37, out_text_channels=64, feature_rotate=False, rotate_train=3.):
+        super().__init__()
+        in_planes = 4 if mask else 3
+        assert math.log(scale_factor, 2) % 1 == 0
+        # what the hand-written kernels are built for (the only configuration the reference constructs,
+        # interfaces/base.py:179-181); fail loudly instead of silently computing something else
+        if not (scale_factor == 2 and hidden_units == 32 and out_text_channels == 64 and mask
+                and (height, width) == (32, 128)):
+            raise NotImplementedError("tatt_amd kernels are specialised for scale 2, 4-channel 16x64 -> 32x128, hidden_units 32")
+        self.block1 = nn.Sequential(nn.Conv2d(in_planes, 2 * hidden_units, kernel_size=9, padding=4), nn.PReLU())
+        self.srb_nums = srb_nums
+        for i in range(srb_nums):
+            setattr(self, 'block%d' % (i + 2), RecurrentResidualBlockTL(2 * hidden_units, out_text_channels))
+        self.text_embedding = text_embedding
+        self.infoGen = TPInterpreter(text_embedding, out_text_channels,
+                                     output_size=(height // scale_factor, width // scale_factor))
+        self.feature_rotate, self.rotate_train = feature_rotate, rotate_train
+        setattr(self, 'block%d' % (srb_nums + 2), nn.Sequential(
+            nn.Conv2d(2 * hidden_units, 2 * hidden_units, kernel_size=3, padding=1), nn.BatchNorm2d(2 * hidden_units)))
+        setattr(self, 'block%d' % (srb_nums + 3), nn.Sequential(
+            UpsampleBLock(2 * hidden_units, 2), nn.Conv2d(2 * hidden_units, in_planes, kernel_size=9, padding=4)))
+        self.tps_inputsize = [height // scale_factor, width // scale_factor]
+        self.stn = STN
+        if self.stn:
+            self.tps = TPSSpatialTransformer(output_image_size=tuple(self.tps_inputsize), num_control_points=20,
+                                             margins=(0.05, 0.05))
+            self.stn_head = STNHead(in_planes=in_planes, num_ctrlpoints=20, activation='none', input_size=self.tps_inputsize)
+        self.block_range = [k for k in range(2, self.srb_nums + 2)]
+        self.in_planes = in_planes
+        # dropout control of the HIP path: p follows the reference (0.1) in training; the seed advances per call
+        self.dropout_p = 0.1
+        self.dropout_seed = 0
+        self._engine = None
+
+    # ------------------------------------------------------------------------------------------------
+    def engine(self):
+        from ..engine import Engine
+        if self._engine is None:
+            self._engine = Engine(self)
+        return self._engine
+
+    def forward(self, x, text_emb=None):
+        """x: LR image with mask [B,4,16,64]; text_emb: recogniser prior [B,K,1,26] (None -> zeros).
+        Returns sigmoid output [B,4,32,128] attached to autograd (model/tsrn.py:648-684)."""
+        from ..engine import TSRNFunction
+        if not x.is_cuda:
+            raise RuntimeError("tatt_amd.TSRN_TL_TRANS runs on the GPU only (no CPU fallback): move model and inputs to cuda")
+        if text_emb is None:
+            text_emb = torch.zeros(x.shape[0], self.text_embedding, 1, 26, device=x.device)
+        eng = self.engine()
+        seed = self.dropout_seed
+        if self.training:
+            self.dropout_seed += 1
+        params = eng.param_list()
+        return TSRNFunction.apply(eng, x, text_emb, self.training, seed, *params)
