@@ -66,8 +66,8 @@ def test_losses_and_metrics():
     sr, sr2 = torch.from_numpy(g["noise_sr"]), torch.from_numpy(g["noise_sr2"])
     arc = torch.from_numpy(g["arc"])
     np.testing.assert_allclose(R.image_loss(sr, hr).numpy(), g["image_loss"], rtol=1e-5)
-    np.testing.assert_allclose(R.rotate(hr, arc).numpy(), g["rot_hr"], atol=2e-6)
-    np.testing.assert_allclose(R.rotate(lr, arc).numpy(), g["rot_lr"], atol=2e-6)
+    np.testing.assert_allclose(R.rotate(hr, arc).numpy(), g["rot_hr"], atol=2e-5)
+    np.testing.assert_allclose(R.rotate(lr, arc).numpy(), g["rot_lr"], atol=2e-5)
     np.testing.assert_allclose(R.tri_ssim(sr, sr2, hr).item(), g["tri_ssim"], rtol=1e-5)
     np.testing.assert_allclose(R.ssim(sr, hr).item(), g["ssim"], rtol=1e-5)
     np.testing.assert_allclose(R.psnr(sr, hr).item(), g["psnr"], rtol=1e-6)
