@@ -1,0 +1,165 @@
+"""End-to-end parity of the HIP path (tatt_amd.model.tsrn.TSRN_TL_TRANS on cuda:0) against
+ (1) the golden vectors generated from the real reference modules (fp32 and fp64 runs), and
+ (2) the CPU oracle on the same seeded inputs (incl. dropout through the shared counter-based masks),
+plus size-independent properties at the BASELINE batch size.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import procgen, tatt_ref as R
+from tests.util import check_against, check_grads, is_buffer, leafify, load_golden, make_state, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+STAGE_TOL = 6e-5     # see tests/test_oracle_golden.py: STN tiny-batch BN + grid_sample amplification in train mode
+
+
+def build(K=37, seed=0):
+    from tatt_amd.model.tsrn import TSRN_TL_TRANS
+    m = TSRN_TL_TRANS(text_embedding=K)
+    m.load_state_dict(procgen.fill_state(m.state_dict(), seed=seed), strict=True)
+    return m.cuda()
+
+
+def nchw(t, B, H=16, W=64):
+    return t.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def stages(ctx, B):
+    tp = ctx["tp"]
+    d = {"block1": nchw(ctx["b1"], B), "tp_map": nchw(ctx["tp_map"], B),
+         "query_pos": tp[8].view(B, 1024, 64).permute(1, 0, 2), "memory": tp[16].view(B, 26, 64).permute(1, 0, 2),
+         "pre_sigmoid": nchw(ctx["tail"][6], B, 32, 128), "block7_in": nchw(ctx["tail"][0], B)}
+    for i, s in enumerate(ctx["srbs"]):
+        if i > 0:
+            d[f"block{i + 1}"] = nchw(s[0], B)
+    d["block6"] = d.pop("block7_in")
+    return d
+
+
+@pytest.mark.parametrize("B", [1, 2, 5])
+def test_eval_forward_vs_reference_golden(B):
+    g = load_golden(f"tsrn_K37_B{B}_eval.npz")
+    m = build().eval()
+    _, lr, tp = procgen.make_inputs(B, 37, seed=0)
+    with torch.no_grad():
+        sr, ctx = m.engine().forward(lr.cuda(), tp.cuda(), False, 0)
+        sr2 = m(lr.cuda(), tp.cuda())
+    assert torch.equal(sr, sr2)
+    check_against(g, "sr", sr, 2e-5, 2e-5)
+    st = stages(ctx, B)
+    for k in ["block1", "query_pos", "memory", "tp_map", "block2", "block6", "pre_sigmoid"]:
+        check_against(g, k, st[k], 2e-5)
+
+
+@pytest.mark.parametrize("K,B", [(37, 2), (37, 5), (2448, 2)])
+def test_train_step_vs_reference_golden(K, B):
+    g = load_golden(f"tsrn_K{K}_B{B}_train.npz")
+    m = build(K).train()
+    m.dropout_p = 0.0                                     # parity is defined with dropout off (goldens too)
+    hr, lr, tp = procgen.make_inputs(B, K, seed=0)
+    sr = m(lr.cuda(), tp.cuda())
+    check_against(g, "sr", sr, STAGE_TOL, 1e-4)
+    from tatt_amd.loss.image_loss import ImageLoss
+    per = ImageLoss(gradient=True, loss_weight=[1, 1e-4])(sr, hr.cuda())
+    np.testing.assert_allclose(per.detach().cpu().numpy(), g["image_loss"], rtol=5e-5)
+    loss = per.mean() * 100
+    loss.backward()
+    grads = {n: p.grad for n, p in m.named_parameters()}
+    check_grads(g, lambda n: None if grads[n] is None else grads[n].cpu())
+    sd = m.state_dict()
+    for k in [k for k in g if k.startswith("bn:")]:
+        check_against(g, k, sd[k[3:]], 2e-5)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_train_fwd_bwd_vs_oracle_with_stages(p):
+    """B=4 against the oracle, stage by stage, with and without dropout (shared hash masks)."""
+    B, K, seed = 4, 37, 5
+    state = make_state(K, seed=1)
+    m = build(K, seed=1).train()
+    hr, lr, tp = procgen.make_inputs(B, K, seed=2)
+    sr, ctx = m.engine().forward(lr.cuda(), tp.cuda(), True, seed, p_drop=p)
+    P = leafify(state)
+    inter = {}
+    sr_o = R.tsrn_forward(P, lr, tp, training=True, drop=R.HashDropout(p, seed) if p > 0 else None, inter=inter)
+    st = stages(ctx, B)
+    ctrl = ctx["stn"][5].view(B, 20, 2)
+    assert rel_l2(ctrl.cpu().numpy(), inter["ctrl_points"].detach().numpy()) < 2e-5
+    for k in ["block1", "query_pos", "memory", "tp_map", "block2", "block4", "block6", "pre_sigmoid"]:
+        r = rel_l2(st[k].cpu().numpy(), inter[k].detach().numpy())
+        assert r < STAGE_TOL, f"{k}: {r:.3e}"
+    assert float((sr.cpu() - sr_o.detach()).abs().max()) < 1e-4
+    # backward through the HIP loss kernel and the engine
+    L = m.engine().L
+    dsr = torch.empty_like(sr)
+    L.image_loss_bwd(sr, hr.cuda(), None, 100.0 / B, dsr, B, 4, 32, 128, 1.0, 1e-4)
+    G = {n: torch.zeros_like(q) for n, q in m.named_parameters()}
+    m.engine().backward(ctx, dsr, G)
+    (R.image_loss(sr_o, hr).mean() * 100).backward()
+    tot = torch.sqrt(sum((P[n].grad.double() ** 2).sum() for n in G if P[n].grad is not None)).item()
+    bad = []
+    for n in G:
+        ref = P[n].grad
+        got = G[n].cpu()
+        if ref is None:
+            assert float(got.abs().max()) == 0.0, n
+            continue
+        err = (got.double() - ref.double()).norm().item()
+        if err > 2e-3 * ref.double().norm().item() + 2e-6 * tot:
+            bad.append((n, err, ref.norm().item()))
+    assert not bad, f"gradient mismatches vs oracle: {bad[:8]}"
+
+
+def test_state_dict_contract_and_buffers():
+    m = build()
+    sd = m.state_dict()
+    assert len(sd) == 304
+    assert sum(q.numel() for q in m.parameters()) == 7608334
+    ref = make_state(37)
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+    # default call used by ptflops in the reference (interfaces/base.py:184-186): text_emb=None, B=1, eval
+    with torch.no_grad():
+        y = m.eval()(torch.rand(1, 4, 16, 64).cuda())
+    assert tuple(y.shape) == (1, 4, 32, 128) and torch.isfinite(y).all()
+
+
+def test_full_batch_properties():
+    """BASELINE config 2 size (B=64): finite outputs in (0,1); per-sample independence of the eval path
+    (sample i of a batch == the same sample in a batch of 1 is NOT expected because the RPE recurs over the
+    batch axis — SURVEY §8a a7 — so instead check prefix consistency: the forward direction of the RPE makes
+    query_pos of sample 0 depend on nothing else)."""
+    B = 64
+    m = build().train()
+    hr, lr, tp = procgen.make_inputs(B, 37, seed=4)
+    sr = m(lr.cuda(), tp.cuda())
+    assert tuple(sr.shape) == (B, 4, 32, 128)
+    assert torch.isfinite(sr).all() and float(sr.min()) > 0 and float(sr.max()) < 1
+    from tatt_amd.loss.image_loss import ImageLoss
+    loss = ImageLoss(gradient=True, loss_weight=[1, 1e-4])(sr, hr.cuda()).mean() * 100
+    loss.backward()
+    for n, q in m.named_parameters():
+        if q.grad is not None:
+            assert torch.isfinite(q.grad).all(), n
+    # linearity of the backward pass in dsr: grads(2*dsr) == 2*grads(dsr)
+    eng = m.engine()
+    sr2, ctx = eng.forward(lr.cuda(), tp.cuda(), True, 0, p_drop=0.0)
+    d = torch.randn_like(sr2)
+    G1 = {n: torch.zeros_like(q) for n, q in m.named_parameters()}
+    G2 = {n: torch.zeros_like(q) for n, q in m.named_parameters()}
+    eng.backward(ctx, d, G1)
+    eng.backward(ctx, 2 * d, G2)
+    for n in ["block1.0.weight", "block4.conv2.weight", "infoGen.init_factor.weight", "stn_head.stn_fc2.weight"]:
+        assert rel_l2((2 * G1[n]).cpu().numpy(), G2[n].cpu().numpy()) < 1e-5, n
+
+
+def test_eval_matches_oracle_B16():
+    """BASELINE config 1 shape (B=16 eval) against the oracle."""
+    B = 16
+    m = build().eval()
+    _, lr, tp = procgen.make_inputs(B, 37, seed=6)
+    with torch.no_grad():
+        sr = m(lr.cuda(), tp.cuda())
+        ref = R.tsrn_forward(make_state(37), lr, tp, training=False, fused_rnn=True)
+    assert float((sr.cpu() - ref).abs().max()) < 2e-5

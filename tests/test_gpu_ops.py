@@ -1,0 +1,365 @@
+"""Per-kernel parity: every C-ABI entry point against a plain torch-CPU fp32/fp64 statement of the same op
+(or the oracle's restatement), on seeded inputs.  GPU only; calls go through the C-ABI (tatt_amd.lib)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tatt_ref as R
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5   # fp32 MFMA = exact fp32 fma chains; only the summation order differs from the CPU reference
+
+
+def L():
+    from tatt_amd.lib import lib
+    return lib()
+
+
+def cu(t):
+    return t.contiguous().cuda()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def close(got, ref, tol=TOL, what=""):
+    r = rel_l2(got.detach().cpu().double().numpy(), ref.detach().double().numpy())
+    assert r <= tol, f"{what}: rel-L2 {r:.3e} > {tol}"
+    assert torch.isfinite(got).all(), what
+
+
+def ws(n=8 << 20):
+    return torch.empty(n, device="cuda")
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(300, 64, 37), (1000, 96, 64), (64, 1536, 512), (52, 64, 2448), (7, 40, 512), (128, 64, 32)])
+def test_gemm_nt_bias_relu_acc(M, N, K):
+    A, B_, bias, C0 = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2), rnd(M, N, seed=3)
+    ref = A.double() @ B_.double().t() + bias.double()
+    out = torch.empty(M, N, device="cuda")
+    L().gemm(cu(A), cu(B_), out, cu(bias), M, N, K, K, 1, K, 1, N, 1, 0, 0, 0, 0, 0, 1, None)
+    close(out, ref, what="nt")
+    out2 = cu(C0)
+    L().gemm(cu(A), cu(B_), out2, cu(bias), M, N, K, K, 1, K, 1, N, 1, 0, 0, 0, 1, 1, 1, None)
+    close(out2, torch.relu(ref + C0.double()), what="nt+acc+relu")
+
+
+def test_gemm_nn_tn_splitk_batched():
+    R_, N, K = 4100, 96, 64
+    dy, W, x = rnd(R_, N), rnd(N, K, seed=1), rnd(R_, K, seed=2)
+    dx = torch.empty(R_, K, device="cuda")
+    L().gemm(cu(dy), cu(W), dx, None, R_, K, N, N, 1, 1, K, K, 1, 0, 0, 0, 0, 0, 1, None)      # dx = dy @ W
+    close(dx, dy.double() @ W.double(), what="nn")
+    for sk in (1, 5, 16):
+        dW = cu(torch.ones(N, K))
+        L().gemm(cu(dy), cu(x), dW, None, N, K, R_, 1, N, 1, K, K, 1, 0, 0, 0, 1, 0, sk, ws())   # dW += dy^T x
+        close(dW, 1 + dy.double().t() @ x.double(), what=f"tn splitk {sk}")
+    # strided sub-blocks (ld > width), as the GRU gradient GEMMs use them
+    big = rnd(R_, 192, seed=5)
+    hp = rnd(R_, 64, seed=6)
+    dW = cu(torch.zeros(96, 32))
+    L().gemm(cu(big)[:, 96:], cu(hp)[:, 32:], dW, None, 96, 32, R_, 1, 192, 1, 64, 32, 1, 0, 0, 0, 1, 0, 8, ws())
+    close(dW, big[:, 96:].double().t() @ hp[:, 32:].double(), what="tn strided")
+    # batched (the RPE recurrence step)
+    h, Wh = rnd(2, 64, 512, seed=7), rnd(2, 1536, 512, seed=8, scale=0.05)
+    gh = torch.empty(2, 64, 1536, device="cuda")
+    L().gemm(cu(h), cu(Wh), gh, None, 64, 1536, 512, 512, 1, 512, 1, 1536, 2, 64 * 512, 1536 * 512, 64 * 1536, 0, 0, 1, None)
+    close(gh, torch.einsum("bmk,bnk->bmn", h.double(), Wh.double()), what="batched")
+
+
+CONVS = [(2, 16, 64, 64, 64, 3), (2, 16, 64, 4, 64, 9), (1, 32, 128, 64, 4, 9), (3, 8, 32, 32, 64, 3),
+         (2, 1, 2, 256, 256, 3), (2, 16, 64, 64, 256, 3), (5, 2, 8, 128, 256, 3)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", CONVS)
+def test_conv_fwd_dgrad_wgrad(B, H, W, Cin, Cout, k):
+    x = rnd(B, Cin, H, W).requires_grad_(True)
+    w = (rnd(Cout, Cin, k, k, seed=1) / math.sqrt(Cin * k * k)).requires_grad_(True)
+    b = rnd(Cout, seed=2).requires_grad_(True)
+    y = F.conv2d(x.double(), w.double(), b.double(), padding=k // 2)
+    dy = rnd(B, Cout, H, W, seed=3)
+    y.backward(dy.double())
+    xn, dyn = cu(x.detach().permute(0, 2, 3, 1)), cu(dy.permute(0, 2, 3, 1))
+    T = k * k
+    out = torch.empty(B, H, W, Cout, device="cuda")
+    L().conv_fwd(xn, cu(w.detach()), cu(b.detach()), out, B, H, W, Cin, Cout, k, k, Cin, Cout, Cin * T, T, 0, 1, 0, 0)
+    close(out.permute(0, 3, 1, 2), y, what="fwd")
+    dx = torch.empty(B, H, W, Cin, device="cuda")
+    L().conv_fwd(dyn, cu(w.detach()), None, dx, B, H, W, Cout, Cin, k, k, Cout, Cin, T, Cin * T, T - 1, -1, 0, 0)
+    close(dx.permute(0, 3, 1, 2), x.grad, what="dgrad")
+    for sk in (1, 4):
+        dW = torch.zeros(Cout, Cin, k, k, device="cuda")
+        L().conv_wgrad(xn, dyn, dW, B, H, W, Cin, Cout, k, k, Cin, Cout, sk, ws(), 1)
+        close(dW, w.grad, what=f"wgrad sk={sk}")
+    db = torch.zeros(Cout, device="cuda")
+    L().colsum(dyn, Cout, B * H * W, Cout, db, 1, ws())
+    close(db, b.grad, what="dbias")
+
+
+@pytest.mark.parametrize("R_,C,act", [(2048, 64, 2), (100, 32, 1), (4, 512, 1), (20000, 256, 0), (4, 256, 1)])
+def test_batchnorm_train_fwd_bwd(R_, C, act):
+    x = (rnd(R_, C) * 2 + 0.5).requires_grad_(True)
+    g_, b_ = (1 + 0.2 * rnd(C, seed=1)).requires_grad_(True), rnd(C, seed=2).requires_grad_(True)
+    rm, rv = rnd(C, seed=3) * 0.1, 1 + 0.3 * torch.rand(C)
+    rm_ref, rv_ref = rm.clone().double(), rv.clone().double()
+    y = F.batch_norm(x.double(), rm_ref, rv_ref, g_.double(), b_.double(), True, 0.1, 1e-5)
+    fa = {0: lambda t: t, 1: torch.relu, 2: R.mish}[act]
+    ya = fa(y)
+    dy = rnd(R_, C, seed=4)
+    ya.backward(dy.double())
+    stat = torch.empty(2, C, device="cuda")
+    rmd, rvd = cu(rm), cu(rv)
+    w = ws()
+    L().bn_stats(cu(x.detach()), C, R_, C, 1e-5, 0.1, stat, rmd, rvd, w)
+    out = torch.empty(R_, C, device="cuda")
+    L().bn_apply(cu(x.detach()), C, stat, cu(g_.detach()), cu(b_.detach()), None, C, out, C, R_, C, act)
+    close(out, ya, what="bn fwd")
+    close(rmd, rm_ref, 1e-5, "running_mean")
+    close(rvd, rv_ref, 1e-5, "running_var")
+    dx, dg, db = torch.empty(R_, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    L().bn_bwd(cu(x.detach()), C, cu(dy), C, stat, cu(g_.detach()), cu(b_.detach()), dx, C, dg, db, R_, C, act, 1, 1, 0, w)
+    tol = 2e-4 if R_ <= 4 else 5e-5          # 4-row batches: xhat = +-1, differences of nearly equal numbers
+    close(dx, x.grad, tol, "bn dx")
+    close(dg, g_.grad, tol, "bn dgamma")
+    close(db, b_.grad, tol, "bn dbeta")
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_layernorm_residual_dropout(p):
+    rows = 1000
+    x, res = rnd(rows, 64).requires_grad_(True), rnd(rows, 64, seed=1).requires_grad_(True)
+    g_, b_ = (1 + 0.2 * rnd(64, seed=2)).requires_grad_(True), rnd(64, seed=3).requires_grad_(True)
+    drop = R.HashDropout(p, 7)
+    mask = drop.mask("enc_drop1", (rows, 64)) if p > 0 else torch.ones(rows, 64)
+    v = x.double() + res.double() * mask.double()
+    y = F.layer_norm(v, (64,), g_.double(), b_.double())
+    dy = rnd(rows, 64, seed=4)
+    y.backward(0.5 * dy.double())
+    ss = (7 * 0x85EBCA77 + R.DROP_SITES["enc_drop1"] * 0xC2B2AE3D) & 0xFFFFFFFF
+    cfg = (ss, int(p * (1 << 24)), 1 / (1 - p)) if p > 0 else (0, 0, 1.0)
+    vout, out = torch.empty(rows, 64, device="cuda"), torch.empty(rows, 64, device="cuda")
+    L().ln_fwd(cu(x.detach()), cu(res.detach()), *cfg, cu(g_.detach()), cu(b_.detach()), vout, out, rows, 1e-5)
+    close(out, y, what="ln fwd")
+    close(vout, v, what="ln v")
+    dv, dres = torch.empty(rows, 64, device="cuda"), torch.empty(rows, 64, device="cuda")
+    dg, db = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    L().ln_bwd(vout, cu(dy), 0.5, cu(g_.detach()), dv, 0, dres, *cfg, dg, db, 1, rows, 1e-5, ws())
+    close(dv, x.grad, 5e-5, "ln dx")
+    close(dres, res.grad, 5e-5, "ln dres")
+    close(dg, g_.grad, 5e-5, "ln dgamma")
+    close(db, b_.grad, 5e-5, "ln dbeta")
+
+
+@pytest.mark.parametrize("vertical", [False, True])
+def test_gru32_fwd_bwd(vertical):
+    B, H, W = 2, 16, 64
+    P = {}
+    for sfx in ("", "_reverse"):
+        P["weight_ih_l0" + sfx] = rnd(96, 64, seed=len(sfx)) * 0.2
+        P["weight_hh_l0" + sfx] = rnd(96, 32, seed=1 + len(sfx)) * 0.3
+        P["bias_ih_l0" + sfx] = rnd(96, seed=2 + len(sfx)) * 0.1
+        P["bias_hh_l0" + sfx] = rnd(96, seed=3 + len(sfx)) * 0.1
+    P = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    x = rnd(B, H, W, 64, seed=9).double().requires_grad_(True)             # NHWC
+    seq = x.permute(0, 2, 1, 3).reshape(B * W, H, 64) if vertical else x.reshape(B * H, W, 64)
+    o = R.bigru(P, "", seq)
+    o = o.view(B, W, H, 64).permute(0, 2, 1, 3) if vertical else o.view(B, H, W, 64)
+    dout = rnd(B, H, W, 64, seed=10)
+    o.backward(dout.double())
+    Rr = B * H * W
+    gi = torch.empty(Rr, 192, device="cuda")
+    xd = cu(x.detach().float().reshape(Rr, 64))
+    f32 = lambda k: cu(P[k].detach().float())
+    for d, sfx in enumerate(("", "_reverse")):
+        L().gemm(xd, f32("weight_ih_l0" + sfx), gi.view(-1)[96 * d:], f32("bias_ih_l0" + sfx), Rr, 96, 64, 64, 1, 64, 1, 192, 1, 0, 0,
+                 0, 0, 0, 1, None)
+    sm = (B * W, H, W, H * W, 1, W) if vertical else (B * H, W, 1, W, 0, 1)
+    out, sv = torch.empty(Rr, 64, device="cuda"), torch.empty(Rr, 2, 4, 32, device="cuda")
+    L().gru32_fwd(gi, f32("weight_hh_l0"), f32("weight_hh_l0_reverse"), f32("bias_hh_l0"), f32("bias_hh_l0_reverse"), out, sv, *sm)
+    close(out.view(B, H, W, 64), o, what="gru fwd")
+    dgi, dgh, hp = torch.empty(Rr, 192, device="cuda"), torch.empty(Rr, 192, device="cuda"), torch.empty(Rr, 64, device="cuda")
+    L().gru32_bwd(cu(dout.reshape(Rr, 64)), out, sv, f32("weight_hh_l0"), f32("weight_hh_l0_reverse"), dgi, dgh, hp, *sm)
+    dx = torch.zeros(Rr, 64, device="cuda")
+    for d, sfx in enumerate(("", "_reverse")):
+        dW = torch.zeros(96, 32, device="cuda")
+        L().gemm(dgh.view(-1)[96 * d:], hp.view(-1)[32 * d:], dW, None, 96, 32, Rr, 1, 192, 1, 64, 32, 1, 0, 0, 0, 1, 0, 4, ws())
+        close(dW, P["weight_hh_l0" + sfx].grad, 5e-5, "dW_hh" + sfx)
+        dWi = torch.zeros(96, 64, device="cuda")
+        L().gemm(dgi.view(-1)[96 * d:], xd, dWi, None, 96, 64, Rr, 1, 192, 1, 64, 64, 1, 0, 0, 0, 1, 0, 4, ws())
+        close(dWi, P["weight_ih_l0" + sfx].grad, 5e-5, "dW_ih" + sfx)
+        db = torch.zeros(96, device="cuda")
+        L().colsum(dgh.view(-1)[96 * d:], 192, Rr, 96, db, 1, ws())
+        close(db, P["bias_hh_l0" + sfx].grad, 5e-5, "db_hh" + sfx)
+        L().gemm(dgi.view(-1)[96 * d:], f32("weight_ih_l0" + sfx), dx, None, Rr, 64, 96, 192, 1, 1, 64, 64, 1, 0, 0, 0, 1, 0, 1, None)
+    close(dx.view(B, H, W, 64), x.grad, 5e-5, "gru dx")
+
+
+@pytest.mark.parametrize("Lq,p", [(1024, 0.0), (26, 0.0), (1024, 0.1), (100, 0.1)])
+def test_attention_fwd_bwd(Lq, p):
+    B = 3
+    Q, K_, V = [rnd(B * n, 64, seed=s).double().requires_grad_(True) for n, s in ((Lq, 1), (26, 2), (26, 3))]
+    drop = R.HashDropout(p, 11)
+    q = (Q.view(B, Lq, 4, 16).permute(0, 2, 1, 3)) * 0.25
+    k = K_.view(B, 26, 4, 16).permute(0, 2, 1, 3)
+    v = V.view(B, 26, 4, 16).permute(0, 2, 1, 3)
+    att = torch.softmax(q @ k.transpose(-1, -2), -1)
+    if p > 0:
+        att = att * drop.mask("dec0_attn", tuple(att.shape)).double()
+    ctx = (att @ v).permute(0, 2, 1, 3).reshape(B * Lq, 64)
+    dctx = rnd(B * Lq, 64, seed=4)
+    ctx.backward(dctx.double())
+    ss = (11 * 0x85EBCA77 + R.DROP_SITES["dec0_attn"] * 0xC2B2AE3D) & 0xFFFFFFFF
+    cfg = (ss, int(p * (1 << 24)), 1 / (1 - p)) if p > 0 else (0, 0, 1.0)
+    Qd, Kd, Vd = [cu(t.detach().float()) for t in (Q, K_, V)]
+    out, pw = torch.empty(B * Lq, 64, device="cuda"), torch.empty(B, 4, Lq, 26, device="cuda")
+    L().attn_fwd(Qd, Kd, Vd, out, pw, B, Lq, 26, *cfg)
+    close(out, ctx, what="attn fwd")
+    close(pw, att, what="attn weights")
+    avg = torch.empty(B, Lq, 26, device="cuda")
+    L().attn_avg(pw, avg, B, Lq)
+    close(avg, att.mean(1), what="attn avg")
+    dQ, dK, dV = torch.empty(B * Lq, 64, device="cuda"), torch.empty(B * 26, 64, device="cuda"), torch.empty(B * 26, 64, device="cuda")
+    L().attn_bwd(Qd, Kd, Vd, cu(dctx), dQ, dK, dV, B, Lq, 26, *cfg, 0)
+    close(dQ, Q.grad, 5e-5, "dQ")
+    close(dK, K_.grad, 5e-5, "dK")
+    close(dV, V.grad, 5e-5, "dV")
+
+
+def test_elementwise_layout_kernels():
+    B, C, H, W = 2, 64, 16, 64
+    x = rnd(B, C, H, W)
+    y = torch.empty(B, H, W, C, device="cuda")
+    L().nchw_to_nhwc(cu(x), y, B, C, H * W)
+    assert torch.equal(y.cpu(), x.permute(0, 2, 3, 1).contiguous())
+    z = torch.empty(B, C, H, W, device="cuda")
+    L().nhwc_to_nchw(y, z, B, C, H * W)
+    assert torch.equal(z.cpu(), x)
+    # prelu fwd/bwd
+    xx = rnd(5000).requires_grad_(True)
+    a = torch.tensor([0.2], requires_grad=True)
+    o = F.prelu(xx, a)
+    dy = rnd(5000, seed=1)
+    o.backward(dy)
+    od = torch.empty(5000, device="cuda")
+    L().prelu_fwd(cu(xx.detach()), cu(a.detach()), od, 5000)
+    assert torch.equal(od.cpu(), o.detach())
+    dxd, da = torch.empty(5000, device="cuda"), torch.zeros(1, device="cuda")
+    L().prelu_bwd(cu(xx.detach()), cu(a.detach()), cu(dy), dxd, da, 1, 5000, ws())
+    close(dxd, xx.grad, what="prelu dx")
+    close(da, a.grad, 1e-4, "prelu dslope")
+    # pixel shuffle + mish
+    u = rnd(B, 256, H, W).double().requires_grad_(True)
+    ps = R.mish(F.pixel_shuffle(u, 2))
+    dps = rnd(B, 64, 2 * H, 2 * W, seed=2)
+    ps.backward(dps.double())
+    un = cu(u.detach().float().permute(0, 2, 3, 1))
+    up = torch.empty(B, 2 * H, 2 * W, 64, device="cuda")
+    L().pixshuf_mish_fwd(un, up, B, H, W, 64)
+    close(up.permute(0, 3, 1, 2), ps, what="pixshuf fwd")
+    du = torch.empty(B, H, W, 256, device="cuda")
+    L().pixshuf_mish_bwd(un, cu(dps.permute(0, 2, 3, 1)), du, B, H, W, 64)
+    close(du.permute(0, 3, 1, 2), u.grad, what="pixshuf bwd")
+    # sigmoid + layout
+    pre = rnd(B, 2 * H, 2 * W, 4).double().requires_grad_(True)
+    sr = torch.sigmoid(pre.permute(0, 3, 1, 2))
+    dsr = rnd(B, 4, 2 * H, 2 * W, seed=3)
+    sr.backward(dsr.double())
+    srd = torch.empty(B, 4, 2 * H, 2 * W, device="cuda")
+    L().sigmoid_to_nchw(cu(pre.detach().float()), srd, B, 4, 4 * H * W)
+    close(srd, sr, what="sigmoid")
+    dpre = torch.empty(B, 2 * H, 2 * W, 4, device="cuda")
+    L().sigmoid_bwd_to_nhwc(srd, cu(dsr), dpre, B, 4, 4 * H * W)
+    close(dpre, pre.grad, what="sigmoid bwd")
+    # max pool
+    for kh, kw in ((2, 2), (1, 2)):
+        m = rnd(B, 32, 4, 16, seed=kh).requires_grad_(True)
+        mp = F.max_pool2d(m, (kh, kw), (kh, kw))
+        dmp = rnd(*mp.shape, seed=5)
+        mp.backward(dmp)
+        mn = cu(m.detach().permute(0, 2, 3, 1))
+        mo = torch.empty(B, 4 // kh, 16 // kw, 32, device="cuda")
+        L().maxpool_fwd(mn, mo, B, 4, 16, 32, kh, kw)
+        assert torch.equal(mo.permute(0, 3, 1, 2).cpu(), mp.detach())
+        dm = torch.empty(B, 4, 16, 32, device="cuda")
+        L().maxpool_bwd(mn, cu(dmp.permute(0, 2, 3, 1)), dm, B, 4, 16, 32, kh, kw)
+        assert torch.equal(dm.permute(0, 3, 1, 2).cpu(), m.grad)
+    # axpby, colsum, tp rows, pe
+    a_, b_ = rnd(1000), rnd(1000, seed=1)
+    o_ = cu(torch.ones(1000))
+    L().axpby(cu(a_), 2.0, cu(b_), -0.5, o_, 1000, 1)
+    close(o_, 1 + 2 * a_ - 0.5 * b_, what="axpby")
+    for R_, C_ in ((3000, 96), (70000, 64), (5, 1536), (9, 40)):
+        xc = rnd(R_, C_ + 8)
+        oc = torch.zeros(C_, device="cuda")
+        L().colsum(cu(xc), C_ + 8, R_, C_, oc, 1, ws())
+        close(oc, xc[:, :C_].double().sum(0), 1e-5, f"colsum {R_}x{C_}")
+    tp = torch.softmax(rnd(26, 3, 37), -1).permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)     # the reference's non-contiguous view
+    rows = torch.empty(3 * 26, 37, device="cuda")
+    tpd = tp.cuda()
+    assert tpd.stride() == tp.stride()
+    L().tp_rows(tpd, tpd.stride(0), tpd.stride(1), tpd.stride(3), rows, 3, 37, 26)
+    assert torch.equal(rows.cpu().view(3, 26, 37), tp.permute(0, 3, 1, 2).squeeze(-1))
+
+
+def test_tps_rotate_loss_adam():
+    B, H, W = 3, 16, 64
+    bufs = R.tps_buffers()
+    x = torch.rand(B, 4, H, W)
+    ctrl = (bufs["target_control_points"].unsqueeze(0) + 0.08 * rnd(B, 20, 2)).double().requires_grad_(True)
+    P = {"tps." + k: v.double() for k, v in bufs.items()}
+    out, _ = R.tps_forward(P, x.double(), ctrl)
+    dy = rnd(B, 4, H, W, seed=1)
+    out.backward(dy.double())
+    T = (bufs["target_coordinate_repr"].double() @ bufs["inverse_kernel"].double()[:, :20]).float()
+    y = torch.empty(B, H, W, 4, device="cuda")
+    cd = cu(ctrl.detach().float().reshape(B, 40))
+    L().tps_sample_fwd(cu(x), cd, cu(T), y, None, B, 4, H, W)
+    close(y.permute(0, 3, 1, 2), out, 2e-5, "tps fwd")
+    dc = torch.empty(B, 40, device="cuda")
+    L().tps_sample_bwd(cu(x), cd, cu(T), cu(dy.permute(0, 2, 3, 1)), dc, B, 4, H, W, 0)
+    close(dc.view(B, 20, 2), ctrl.grad, 2e-4, "tps dctrl")
+    # rotation (TSC deformation)
+    img = torch.rand(B, 4, 32, 128).double().requires_grad_(True)
+    arc = torch.tensor([0.1, -0.17, 0.05])
+    rot = R.rotate(img, arc.double())
+    drot = rnd(B, 4, 32, 128, seed=2)
+    rot.backward(drot.double())
+    ro = torch.empty(B, 4, 32, 128, device="cuda")
+    L().rotate_fwd(cu(img.detach().float()), cu(arc), ro, B, 4, 32, 128)
+    assert float((ro.cpu() - rot.detach().float()).abs().max()) < 2e-5
+    dimg = torch.zeros(B, 4, 32, 128, device="cuda")
+    L().rotate_bwd(cu(arc), cu(drot), dimg, B, 4, 32, 128)
+    close(dimg, img.grad, 5e-5, "rotate bwd")
+    # image loss
+    hr = torch.rand(B, 4, 32, 128)
+    sr = (hr + 0.1 * rnd(B, 4, 32, 128, seed=3)).clamp(0, 1).double().requires_grad_(True)
+    per = R.image_loss(sr, hr.double())
+    (per.mean() * 100).backward()
+    pd = torch.empty(B, device="cuda")
+    L().image_loss_fwd(cu(sr.detach().float()), cu(hr), pd, B, 4, 32, 128, 1.0, 1e-4)
+    close(pd, per, 1e-5, "image loss")
+    dsr = torch.empty(B, 4, 32, 128, device="cuda")
+    L().image_loss_bwd(cu(sr.detach().float()), cu(hr), None, 100.0 / B, dsr, B, 4, 32, 128, 1.0, 1e-4)
+    close(dsr, sr.grad, 5e-5, "image loss bwd")
+    # clip + adam (two steps)
+    n = 100000
+    p0, g1, g2 = rnd(n), rnd(n, seed=1) * 0.01, rnd(n, seed=2) * 0.0001
+    pr = p0.clone()
+    st = {}
+    tot1 = R.clip_and_adam([pr], [g1.clone()], st, 1)
+    tot2 = R.clip_and_adam([pr], [g2.clone()], st, 2)
+    pd_, m_, v_, state = cu(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(8, device="cuda")
+    w = ws()
+    L().clip_adam(pd_, cu(g1), m_, v_, n, 1e-3, 0.5, 0.999, 1e-8, 0.25, state, w)
+    assert abs(state[0].item() - float(tot1)) < 1e-4 * float(tot1)
+    L().clip_adam(pd_, cu(g2), m_, v_, n, 1e-3, 0.5, 0.999, 1e-8, 0.25, state, w)
+    assert abs(state[0].item() - float(tot2)) < 1e-4 * float(tot2)
+    assert float((pd_.cpu() - pr).abs().max()) < 2e-6
