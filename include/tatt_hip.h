@@ -8,7 +8,8 @@
  *   - return 0 on success, non-zero otherwise (message via tatt_last_error(), thread-local);
  *   - activations are NHWC ("rows x channels": row = (batch, y, x)); `ld*` = floats between rows;
  *   - dropout sites take (seed_site, thresh, scale): keep iff (hash(seed_site, index) >> 8) >= thresh,
- *     kept values are multiplied by scale = 1/(1-p); thresh == 0 disables dropout.
+ *     kept values are multiplied by scale = 1/(1-p); thresh == 0 disables dropout; seed_dev (optional device
+ *     pointer) adds seed_dev[0] to the seed at run time so a captured hipGraph draws new masks per replay.
  * tatt_amd/lib.py parses this header to build the ctypes signatures: keep one declaration per statement and
  * use only the scalar types  int, long, float, uint32_t, size_t, hipStream_t  and (const) float* / void*.
  */
@@ -51,9 +52,9 @@ int tatt_bn_apply(const float* x, long ldx, const float* stat, const float* gamm
 int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const float* stat, const float* gamma, const float* beta, float* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int act, int train, int accumulate_params, int accumulate_dx, float* workspace, hipStream_t stream);
 
 /* ---- LayerNorm(64) with fused residual + dropout (model/transformer_v2.py:478-482, :827-831, :380) -------- */
-int tatt_ln_fwd(const float* x, const float* res, uint32_t seed_site, uint32_t thresh, float scale, const float* gamma, const float* beta, float* vout, float* y, int rows, float eps, hipStream_t stream);
+int tatt_ln_fwd(const float* x, const float* res, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, const float* gamma, const float* beta, float* vout, float* y, int rows, float eps, hipStream_t stream);
 size_t tatt_ln_workspace(int rows);
-int tatt_ln_bwd(const float* v, const float* dy, float dyscale, const float* gamma, float* dv, int dv_accumulate, float* dres, uint32_t seed_site, uint32_t thresh, float scale, float* dgamma, float* dbeta, int accumulate_params, int rows, float eps, float* workspace, hipStream_t stream);
+int tatt_ln_bwd(const float* v, const float* dy, float dyscale, const float* gamma, float* dv, int dv_accumulate, float* dres, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, float* dgamma, float* dbeta, int accumulate_params, int rows, float eps, float* workspace, hipStream_t stream);
 
 /* ---- BiGRU(64 -> 2x32) recurrence of GruBlock (model/tsrn.py:1080,:1088), persistent half-wave per sequence - */
 int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* out, float* save, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride, hipStream_t stream);
@@ -66,8 +67,8 @@ int tatt_rpe_gather_x(const float* init_factor, float* x, hipStream_t stream);
 int tatt_rpe_scatter_dx(const float* dx, float* dinit, int accumulate, hipStream_t stream);
 
 /* ---- attention core, 4 heads x 16, 26 keys (nn.MultiheadAttention at model/transformer_v2.py:476,:819) ---- */
-int tatt_attn_fwd(const float* Q, const float* Kp, const float* Vp, float* ctx, float* pw, int B, int Lq, int nkeys, uint32_t seed_site, uint32_t thresh, float scale, hipStream_t stream);
-int tatt_attn_bwd(const float* Q, const float* Kp, const float* Vp, const float* dctx, float* dQ, float* dK, float* dV, int B, int Lq, int nkeys, uint32_t seed_site, uint32_t thresh, float scale, int accumulate_kv, hipStream_t stream);
+int tatt_attn_fwd(const float* Q, const float* Kp, const float* Vp, float* ctx, float* pw, int B, int Lq, int nkeys, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t stream);
+int tatt_attn_bwd(const float* Q, const float* Kp, const float* Vp, const float* dctx, float* dQ, float* dK, float* dV, int B, int Lq, int nkeys, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, int accumulate_kv, hipStream_t stream);
 int tatt_attn_avg(const float* pw, float* out, int B, int Lq, hipStream_t stream);
 
 /* ---- element-wise / layout (model/tsrn.py:599 PReLU, :1042-1043 PixelShuffle+mish, :683 sigmoid, :208, :212;
@@ -86,9 +87,10 @@ int tatt_sigmoid_bwd_to_nhwc(const float* sr, const float* dsr, float* dpre, int
 int tatt_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int kh, int kw, hipStream_t stream);
 int tatt_maxpool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int kh, int kw, hipStream_t stream);
 int tatt_tp_rows(const float* tp, long sB, long sK, long sL, float* out, int B, int K, int L, hipStream_t stream);
-int tatt_pe_dropout(const float* pe, float* pos, int B, int L, uint32_t seed_site, uint32_t thresh, float scale, hipStream_t stream);
-int tatt_dropout_mul(const float* x, float* y, long n, uint32_t seed_site, uint32_t thresh, float scale, hipStream_t stream);
-int tatt_relu_drop_bwd(const float* h, const float* dh, float* out, long n, uint32_t seed_site, uint32_t thresh, float scale, hipStream_t stream);
+int tatt_pe_dropout(const float* pe, float* pos, int B, int L, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t stream);
+int tatt_dropout_mul(const float* x, float* y, long n, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t stream);
+int tatt_seed_bump(uint32_t* seed, hipStream_t stream);
+int tatt_relu_drop_bwd(const float* h, const float* dh, float* out, long n, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t stream);
 
 /* ---- TPS rectification = grid build + bilinear gather (model/tps_spatial_transformer.py:97-112, :10-11) and
  *      the TSC rotation (interfaces/super_resolution_eng.py:50-82) ----------------------------------------- */

@@ -47,12 +47,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   }
   const float inv = 1.f / sum;
   const uint32_t ibase = (uint32_t)((((long)b * NH + h) * Lq + q) * S);
+  const uint32_t ss = tatt_eff_seed(dc);
   float o[DH];
 #pragma unroll
   for (int d = 0; d < DH; ++d) o[d] = 0.f;
 #pragma unroll
   for (int k = 0; k < S; ++k) {
-    float pk = p[k] * inv * tatt_drop_mask(dc.seed_site, ibase + k, dc.thresh, dc.scale);
+    float pk = p[k] * inv * tatt_drop_mask(ss, ibase + k, dc.thresh, dc.scale);
     if (pw) pw[(long)ibase + k] = pk;
 #pragma unroll
     for (int d = 0; d < DH; ++d) o[d] += pk * Vs[k * E + h * DH + d];
@@ -110,10 +111,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         const float inv = 1.f / sum;
         const uint32_t ibase = (uint32_t)((((long)b * NH + h) * Lq + q) * S);
         float dot = 0.f;
+        const uint32_t ss = tatt_eff_seed(dc);
 #pragma unroll
         for (int k = 0; k < S; ++k) {
           float pk = pd[k] * inv;
-          float mk = tatt_drop_mask(dc.seed_site, ibase + k, dc.thresh, dc.scale);
+          float mk = tatt_drop_mask(ss, ibase + k, dc.thresh, dc.scale);
           float g = 0.f;
 #pragma unroll
           for (int d = 0; d < DH; ++d) g += dcv[d] * Vs[k * DH + d];
@@ -196,19 +198,20 @@ __global__ void attn_avg_kernel(const float* __restrict__ pw, float* __restrict_
 extern "C" {
 
 int tatt_attn_fwd(const float* Q, const float* Kp, const float* Vp, float* ctx, float* pw, int B, int Lq, int nkeys,
-                  uint32_t seed_site, uint32_t thresh, float scale, hipStream_t st) {
+                  uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t st) {
   TATT_CHECK_ARG(nkeys == S, "tatt_attn_fwd: built for %d keys, got %d", S, nkeys);
   TATT_CHECK_ARG(B > 0 && Lq > 0, "tatt_attn_fwd: bad dims");
-  DropCfg dc{seed_site, thresh, scale};
+  DropCfg dc{seed_site, thresh, scale, seed_dev};
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(Lq, 64), B), dim3(256), 0, st, Q, Kp, Vp, ctx, pw, Lq, dc);
   TATT_LAUNCH_CHECK("attn_fwd");
   return TATT_OK;
 }
 
 int tatt_attn_bwd(const float* Q, const float* Kp, const float* Vp, const float* dctx, float* dQ, float* dK, float* dV, int B,
-                  int Lq, int nkeys, uint32_t seed_site, uint32_t thresh, float scale, int accumulate_kv, hipStream_t st) {
+                  int Lq, int nkeys, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, int accumulate_kv,
+                  hipStream_t st) {
   TATT_CHECK_ARG(nkeys == S, "tatt_attn_bwd: built for %d keys, got %d", S, nkeys);
-  DropCfg dc{seed_site, thresh, scale};
+  DropCfg dc{seed_site, thresh, scale, seed_dev};
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * NH), dim3(256), 0, st, Q, Kp, Vp, dctx, dQ, dK, dV, Lq, dc, accumulate_kv);
   TATT_LAUNCH_CHECK("attn_bwd");
   return TATT_OK;

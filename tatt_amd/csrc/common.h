@@ -57,7 +57,12 @@ struct DropCfg {       // passed by value to kernels
   uint32_t seed_site;  // tatt_seed_site(seed, site)
   uint32_t thresh;     // 0 = dropout off
   float scale;         // 1/(1-p)
+  const uint32_t* seed_dev;  // optional device-resident seed increment (lets a captured hipGraph draw new masks per replay)
 };
+// effective (seed, site) word: seed_site + seed_dev[0]*0x85EBCA77  ==  tatt_seed_site(seed + seed_dev[0], site)
+__device__ __forceinline__ uint32_t tatt_eff_seed(const DropCfg& dc) {
+  return dc.seed_dev ? dc.seed_site + dc.seed_dev[0] * 0x85EBCA77u : dc.seed_site;
+}
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }

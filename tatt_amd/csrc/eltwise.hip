@@ -200,26 +200,38 @@ __global__ void pe_dropout_k(const float* __restrict__ pe, float* __restrict__ p
   if (i >= (long)B * L * 64) return;
   int c = (int)(i % 64);
   int l = (int)((i / 64) % L);
-  pos[i] = pe[l * 64 + c] * tatt_drop_mask(dc.seed_site, (uint32_t)i, dc.thresh, dc.scale);
+  pos[i] = pe[l * 64 + c] * tatt_drop_mask(tatt_eff_seed(dc), (uint32_t)i, dc.thresh, dc.scale);
 }
 
 // y = x * dropmask(i)   (in place allowed)
 __global__ void dropout_mul_k(const float* __restrict__ x, float* __restrict__ y, long n, DropCfg dc) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  y[i] = x[i] * tatt_drop_mask(dc.seed_site, (uint32_t)i, dc.thresh, dc.scale);
+  y[i] = x[i] * tatt_drop_mask(tatt_eff_seed(dc), (uint32_t)i, dc.thresh, dc.scale);
 }
 // FFN hidden backward: dpre = dh * dropmask(i) * (h > 0)   (h = relu output before dropout)
 __global__ void relu_drop_bwd_k(const float* __restrict__ h, const float* __restrict__ dh, float* __restrict__ out, long n,
                                 DropCfg dc) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  out[i] = h[i] > 0.f ? dh[i] * tatt_drop_mask(dc.seed_site, (uint32_t)i, dc.thresh, dc.scale) : 0.f;
+  out[i] = h[i] > 0.f ? dh[i] * tatt_drop_mask(tatt_eff_seed(dc), (uint32_t)i, dc.thresh, dc.scale) : 0.f;
+}
+
+// seed[0] += 1 (one thread): part of a captured training step so that every replay draws fresh dropout masks
+__global__ void seed_bump_k(uint32_t* seed) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) seed[0] += 1u;
 }
 
 }  // namespace
 
 extern "C" {
+
+int tatt_seed_bump(uint32_t* seed, hipStream_t st) {
+  hipLaunchKernelGGL(seed_bump_k, dim3(1), dim3(64), 0, st, seed);
+  TATT_LAUNCH_CHECK("seed_bump");
+  return TATT_OK;
+}
+
 
 int tatt_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, hipStream_t st) {
   hipLaunchKernelGGL(nchw_to_nhwc_k, GRID1D((long)B * C * HW), 0, st, x, y, B, C, HW);
@@ -300,21 +312,21 @@ int tatt_tp_rows(const float* tp, long sB, long sK, long sL, float* out, int B, 
   TATT_LAUNCH_CHECK("tp_rows");
   return TATT_OK;
 }
-int tatt_pe_dropout(const float* pe, float* pos, int B, int L, uint32_t seed_site, uint32_t thresh, float scale, hipStream_t st) {
-  DropCfg dc{seed_site, thresh, scale};
+int tatt_pe_dropout(const float* pe, float* pos, int B, int L, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t st) {
+  DropCfg dc{seed_site, thresh, scale, seed_dev};
   hipLaunchKernelGGL(pe_dropout_k, GRID1D((long)B * L * 64), 0, st, pe, pos, B, L, dc);
   TATT_LAUNCH_CHECK("pe_dropout");
   return TATT_OK;
 }
-int tatt_dropout_mul(const float* x, float* y, long n, uint32_t seed_site, uint32_t thresh, float scale, hipStream_t st) {
-  DropCfg dc{seed_site, thresh, scale};
+int tatt_dropout_mul(const float* x, float* y, long n, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t st) {
+  DropCfg dc{seed_site, thresh, scale, seed_dev};
   hipLaunchKernelGGL(dropout_mul_k, GRID1D(n), 0, st, x, y, n, dc);
   TATT_LAUNCH_CHECK("dropout_mul");
   return TATT_OK;
 }
 int tatt_relu_drop_bwd(const float* h, const float* dh, float* out, long n, uint32_t seed_site, uint32_t thresh, float scale,
-                       hipStream_t st) {
-  DropCfg dc{seed_site, thresh, scale};
+                       const uint32_t* seed_dev, hipStream_t st) {
+  DropCfg dc{seed_site, thresh, scale, seed_dev};
   hipLaunchKernelGGL(relu_drop_bwd_k, GRID1D(n), 0, st, h, dh, out, n, dc);
   TATT_LAUNCH_CHECK("relu_drop_bwd");
   return TATT_OK;

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   if (row >= rows) return;
   long i = (long)row * 64 + lane;
   float v = x[i];
-  if (res) v += res[i] * tatt_drop_mask(dc.seed_site, (uint32_t)i, dc.thresh, dc.scale);
+  if (res) v += res[i] * tatt_drop_mask(tatt_eff_seed(dc), (uint32_t)i, dc.thresh, dc.scale);
   float mean = wave_sum(v) * (1.f / 64.f);
   float d = v - mean;
   float var = wave_sum(d * d) * (1.f / 64.f);
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ v
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int rb = blockIdx.x * rows_per_blk, re = min(rows, rb + rows_per_blk);
   const float ga = gamma[lane];
+  const uint32_t ss = tatt_eff_seed(dc);
   float sg = 0.f, sb = 0.f;
   for (int row = rb + w; row < re; row += 4) {
     long i = (long)row * 64 + lane;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ v
     float m1 = wave_sum(gg) * (1.f / 64.f);
     float m2 = wave_sum(gg * xh) * (1.f / 64.f);
     float o = rstd * (gg - m1 - xh * m2);
-    if (dres) dres[i] = o * tatt_drop_mask(dc.seed_site, (uint32_t)i, dc.thresh, dc.scale);
+    if (dres) dres[i] = o * tatt_drop_mask(ss, (uint32_t)i, dc.thresh, dc.scale);
     if (dv_accumulate) o += dv[i];
     dv[i] = o;
   }
@@ -322,9 +323,10 @@ int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const floa
   return TATT_OK;
 }
 
-int tatt_ln_fwd(const float* x, const float* res, uint32_t seed_site, uint32_t thresh, float scale, const float* gamma,
+int tatt_ln_fwd(const float* x, const float* res, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev,
+                const float* gamma,
                 const float* beta, float* vout, float* y, int rows, float eps, hipStream_t st) {
-  DropCfg dc{seed_site, thresh, scale};
+  DropCfg dc{seed_site, thresh, scale, seed_dev};
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, res, dc, gamma, beta, vout, y, rows, eps);
   TATT_LAUNCH_CHECK("ln_fwd");
   return TATT_OK;
@@ -333,9 +335,10 @@ int tatt_ln_fwd(const float* x, const float* res, uint32_t seed_site, uint32_t t
 size_t tatt_ln_workspace(int rows) { (void)rows; return (size_t)512 * 128; }
 
 int tatt_ln_bwd(const float* v, const float* dy, float dyscale, const float* gamma, float* dv, int dv_accumulate, float* dres,
-                uint32_t seed_site, uint32_t thresh, float scale, float* dgamma, float* dbeta, int accumulate_params, int rows,
+                uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, float* dgamma, float* dbeta,
+                int accumulate_params, int rows,
                 float eps, float* workspace, hipStream_t st) {
-  DropCfg dc{seed_site, thresh, scale};
+  DropCfg dc{seed_site, thresh, scale, seed_dev};
   int nblk = cdiv(rows, 64);
   if (nblk > 512) nblk = 512;
   int rpb = cdiv(rows, nblk);

@@ -20,7 +20,7 @@ DROP_SITES = {
 STN_STAGES = [(0, 4, 32, (2, 2)), (2, 32, 64, (2, 2)), (4, 64, 128, (2, 2)), (6, 128, 256, (2, 2)),
               (8, 256, 256, (1, 2)), (10, 256, 256, None)]
 WS_FLOATS = 48 * 1024 * 1024
-NODROP = (0, 0, 1.0)
+NODROP = (0, 0, 1.0, None)
 
 
 class Ctx:
@@ -45,6 +45,7 @@ class Engine:
         self._names = [n for n, _ in module.named_parameters()]
         self._ptrs = None
         self.P = {}
+        self.seed_dev = None      # optional uint32 device tensor added to the dropout seed (graph-captured training)
 
     # ---- parameters --------------------------------------------------------------------------------
     def param_list(self):
@@ -138,7 +139,7 @@ class Engine:
         if p <= 0.0:
             return NODROP
         ss = (seed * 0x85EBCA77 + DROP_SITES[site] * 0xC2B2AE3D) & 0xFFFFFFFF
-        return (ss, int(p * (1 << 24)), 1.0 / (1.0 - p))
+        return (ss, int(p * (1 << 24)), 1.0 / (1.0 - p), self.seed_dev)
 
     # ---- GRU block (1x1 conv + BiGRU) ------------------------------------------------------------------------
     def _seqmap(self, B, H, W, vertical):

@@ -24,7 +24,7 @@ def test_argument_errors_are_reported_not_thrown():
     with pytest.raises(RuntimeError, match="tatt_gemm"):
         L.gemm(None, None, None, None, 0, 0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1, None, None)
     with pytest.raises(RuntimeError, match="26 keys"):
-        L.attn_fwd(None, None, None, None, None, 1, 8, 25, 0, 0, 1.0, None)
+        L.attn_fwd(None, None, None, None, None, 1, 8, 25, 0, 0, 1.0, None, None)
     assert L.gemm_workspace(64, 64, 4) == 64 * 64 * 4
 
 

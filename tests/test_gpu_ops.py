@@ -144,7 +144,7 @@ def test_layernorm_residual_dropout(p):
     dy = rnd(rows, 64, seed=4)
     y.backward(0.5 * dy.double())
     ss = (7 * 0x85EBCA77 + R.DROP_SITES["enc_drop1"] * 0xC2B2AE3D) & 0xFFFFFFFF
-    cfg = (ss, int(p * (1 << 24)), 1 / (1 - p)) if p > 0 else (0, 0, 1.0)
+    cfg = (ss, int(p * (1 << 24)), 1 / (1 - p), None) if p > 0 else (0, 0, 1.0, None)
     vout, out = torch.empty(rows, 64, device="cuda"), torch.empty(rows, 64, device="cuda")
     L().ln_fwd(cu(x.detach()), cu(res.detach()), *cfg, cu(g_.detach()), cu(b_.detach()), vout, out, rows, 1e-5)
     close(out, y, what="ln fwd")
@@ -217,7 +217,7 @@ def test_attention_fwd_bwd(Lq, p):
     dctx = rnd(B * Lq, 64, seed=4)
     ctx.backward(dctx.double())
     ss = (11 * 0x85EBCA77 + R.DROP_SITES["dec0_attn"] * 0xC2B2AE3D) & 0xFFFFFFFF
-    cfg = (ss, int(p * (1 << 24)), 1 / (1 - p)) if p > 0 else (0, 0, 1.0)
+    cfg = (ss, int(p * (1 << 24)), 1 / (1 - p), None) if p > 0 else (0, 0, 1.0, None)
     Qd, Kd, Vd = [cu(t.detach().float()) for t in (Q, K_, V)]
     out, pw = torch.empty(B * Lq, 64, device="cuda"), torch.empty(B, 4, Lq, 26, device="cuda")
     L().attn_fwd(Qd, Kd, Vd, out, pw, B, Lq, 26, *cfg)
