@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Benchmark of the TATT SR training step on MI355X (BASELINE.json metric: train images/sec, whole node).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload = BASELINE config 2 per GPU: TSRN_TL_TRANS(STN=True, K=37) random init, train mode (dropout 0.1, BN batch
+stats), fp32, batch 64 synthetic TextZoom-shaped images, frozen (precomputed) CRNN-shaped text prior,
+loss = ImageLoss([1,1e-4]).mean()*100, backward, clip_grad_norm 0.25, Adam(1e-3, beta1 .5).  One step = one
+forward + backward + optimiser update over one batch already resident in HBM.  N > 1 = data parallel, one process
+per GPU, bucketed gradient all-reduce (AVG) over RCCL, weak scaling (64 images per GPU).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_IMAGE_TRAIN = 7.70e9        # fwd+bwd, pixel+gradient loss, reference-as-executed
+PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 matrix peak
+
+
+def conv_roofline(L, B, iters=30):
+    """Dominant kernel = the NHWC implicit-GEMM conv (SRB shape 3x3, 64->64, 16x64 maps): 22 of its launches per
+    step.  Timed with events on the launch stream; algorithmic FLOPs = 2 * pixels * Cout * 9*Cin."""
+    x = torch.randn(B, 16, 64, 64, device="cuda")
+    w = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
+    b = torch.randn(64, device="cuda")
+    y = torch.empty(B, 16, 64, 64, device="cuda")
+    args = (x, w, b, y, B, 16, 64, 64, 64, 3, 3, 64, 64, 64 * 9, 9, 0, 1, 0, 0)
+    for _ in range(5):
+        L.conv_fwd(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        L.conv_fwd(*args)
+    e1.record()
+    e1.synchronize()
+    dt = e0.elapsed_time(e1) / iters * 1e-3
+    flops = 2.0 * B * 16 * 64 * 64 * 9 * 64
+    ach = flops / dt / 1e12
+    return {"bound": "mfma", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW> conv3x3 64->64 [B,16,64]", "achieved": round(ach, 2),
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launch_us": round(dt * 1e6, 2), "flop_per_launch": flops}
+
+
+def cpu_baseline(state, B, K, steps=2):
+    """The oracle (CPU restatement of the reference step, stock torch ops) timed on this box's host cores."""
+    from oracle import tatt_ref as R
+    from tatt_amd.data import synthetic_batch
+    hr, lr, tp = synthetic_batch(B, K, seed=123, device="cpu")
+    P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not ("running_" in k or k.startswith("tps.") or k.endswith("pe.pe"))
+             else v.clone()) for k, v in state.items()}
+    st = {}
+    drop = R.HashDropout(0.1, 0)
+    R.train_step_config2(P, lr, hr, tp.contiguous(), st, 1, drop=drop, fused_rnn=True)      # warm-up
+    t0 = time.time()
+    for i in range(steps):
+        R.train_step_config2(P, lr, hr, tp.contiguous(), st, 2 + i, drop=drop, fused_rnn=True)
+    dt = (time.time() - t0) / steps
+    return {"value": round(B / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} training steps of the same config-2 workload (B={B}) after 1 warm-up, torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--K", type=int, default=37)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from tatt_amd.data import synthetic_batch
+    from tatt_amd.lib import lib
+    from tatt_amd.model.tsrn import TSRN_TL_TRANS
+    from tatt_amd.trainer import SRTrainer
+
+    torch.manual_seed(123)
+    model = TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32,
+                          text_embedding=a.K)
+    state_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.cuda().train()
+    trainer = SRTrainer(model, lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, loss_weight=(1.0, 1e-4), use_graph=not a.no_graph)
+    hr, lr, tp = synthetic_batch(a.batch, a.K, seed=123 + rank, device="cuda")
+
+    for _ in range(a.warmup):
+        trainer.step(lr, hr, tp)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        per = trainer.step(lr, hr, tp)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(per.mean().item()) * 100
+    if not (loss == loss and loss < 1e6):
+        raise SystemExit(f"non-finite training loss {loss}")
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = a.batch * world * a.steps / dt
+        out = {
+            "metric": "train images/sec (whole node) TATT 16x64->32x128", "value": round(value, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: TSRN_TL_TRANS(STN, K=%d) single training step fp32, pixel+gradient loss, "
+                                   "clip 0.25 + Adam, frozen text prior" % a.K,
+                       "per_gpu_batch": a.batch, "global_batch": a.batch * world, "lr_shape": [4, 16, 64], "hr_shape": [4, 32, 128],
+                       "parallelism": f"dp{world}", "hip_graph": not a.no_graph, "loss": round(loss, 4)},
+            "model_tflops": round(value * FLOP_PER_IMAGE_TRAIN / 1e12, 2),
+            "model_frac_of_f32_mfma_peak": round(value * FLOP_PER_IMAGE_TRAIN / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+        }
+        out["roofline"] = conv_roofline(lib(), a.batch)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(state_cpu, a.batch, a.K)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,7 @@ class Engine:
         self._names = [n for n, _ in module.named_parameters()]
         self._ptrs = None
         self.P = {}
+        self.debug = None         # set to a dict to stash intermediate gradients (tools/debug_grads.py)
         self.seed_dev = None      # optional uint32 device tensor added to the dropout seed (graph-captured training)
 
     # ---- parameters --------------------------------------------------------------------------------
@@ -56,13 +57,18 @@ class Engine:
         ptrs = tuple(p.data_ptr() for p in ps.values())
         if ptrs != self._ptrs:
             self.P = {k: v.data for k, v in ps.items()}
-            self.P.update({k: v for k, v in self.m.named_buffers()})
             for k, v in self.P.items():
-                if v.is_floating_point() and (not v.is_contiguous() or v.dtype != torch.float32):
+                if not v.is_contiguous() or v.dtype != torch.float32:
                     raise RuntimeError(f"parameter {k} must be contiguous fp32")
             self._ptrs = ptrs
-        else:
-            self.P.update({k: v for k, v in self.m.named_buffers()})
+        for k, v in self.m.named_buffers():
+            if v.is_floating_point() and v.dtype != torch.float32:
+                raise RuntimeError(f"buffer {k} must be fp32")
+            if not v.is_contiguous():
+                if "running_" in k:
+                    raise RuntimeError(f"buffer {k} must be contiguous (it is updated in place)")
+                v = v.contiguous()      # constant buffers (e.g. a column-major tps.inverse_kernel from an old checkpoint)
+            self.P[k] = v
         dev = next(iter(ps.values())).device
         if self.ws is None or self.dev != dev:
             self.dev = dev
@@ -427,8 +433,11 @@ class Engine:
         return sr, ctx
 
     # ================================================================================================================
-    def backward(self, ctx, dsr, G):
-        """Accumulates parameter gradients of one forward call into G (dict name -> fp32 tensor)."""
+    def backward(self, ctx, dsr, G, on_stage=None):
+        """Accumulates parameter gradients of one forward call into G (dict name -> fp32 tensor).
+        on_stage(name) is called when a gradient bucket is complete ("tail", "srbs", "infogen", "head"):
+        the data-parallel trainer starts that bucket's all-reduce there, overlapping the rest of the pass."""
+        on_stage = on_stage or (lambda name: None)
         L, m, P = self.L, self.m, self.P
         B, training, seed, p = ctx["meta"]
         cfg = lambda site: self.dropcfg(site, seed, p)
@@ -454,6 +463,7 @@ class Engine:
         self.conv_wgrad(blk_last, dc7, G[k7 + "0.weight"], G[k7 + "0.bias"], B, H, W, 64, 64, 3)
         dout = self.new(R0, 64)
         self.conv_dgrad(dc7, P[k7 + "0.weight"], dout, B, H, W, 64, 64, 3)
+        on_stage("tail")
 
         # ---- SRBs, last to first ----------------------------------------------------------------------------------
         dtp = self.new(R0, 64)
@@ -476,6 +486,7 @@ class Engine:
             self.conv_dgrad(dca, P[pre + "conv1.weight"], ds, B, H, W, 64, 64, 3, acc=1)     # dx = ds + conv1^T(dca)
             dout = ds
         L.axpby(dout, 1.0, None, 0.0, db1, R0 * 64, 1)
+        on_stage("srbs")
 
         # ---- TP interpreter --------------------------------------------------------------------------------------
         ig, tr = "infoGen.", "infoGen.transformer."
@@ -541,6 +552,7 @@ class Engine:
             self.colsum(dgi_sum[dd], 64, 1536, G[g + "bias_ih_l0" + sfx])
             self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd)
         L.rpe_scatter_dx(dxg, G[ig + "init_factor.weight"], 1)
+        on_stage("infogen")
 
         # ---- block1 ------------------------------------------------------------------------------------------------
         dc1 = self.new(R0, 64)
@@ -548,6 +560,7 @@ class Engine:
         xs = ctx["xs"]
         self.conv_wgrad(xs, dc1, G["block1.0.weight"], G["block1.0.bias"], B, H, W, 4, 64, 9)
         if not ctx["use_stn"]:
+            on_stage("head")
             return
         # ---- TPS + STN head ----------------------------------------------------------------------------------------
         stn_saved, f, l1, stat1, feat01, ctrl, Tm = ctx["stn"]
@@ -577,10 +590,13 @@ class Engine:
             else:
                 da = dh
             dc = self.bn_bwd(pre + "1.", c, da, stat, Rr, cout, 1, True, G)
+            if self.debug is not None:
+                self.debug[f"stn{idx}"] = (dh.clone(), da.clone(), dc.clone())
             self.conv_wgrad(hin, dc, G[pre + "0.weight"], G[pre + "0.bias"], B, hh, ww, cin, cout, 3)
             if idx > 0:
                 dh = self.new(Rr, cin)
                 self.conv_dgrad(dc, P[pre + "0.weight"], dh, B, hh, ww, cin, cout, 3)
+        on_stage("head")
 
 
 # parameters that never receive a gradient in the reference: autograd must see None for them
@@ -594,7 +610,7 @@ class TSRNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(fctx, eng, x, text_emb, training, seed, *params):
-        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need = any(fctx.needs_input_grad)      # grad mode is always off inside Function.forward
         sr, ctx = eng.forward(x, text_emb, training, seed, want_ctx=True)
         fctx.eng, fctx.c, fctx.need = eng, ctx if need else None, need
         fctx.names = eng._names

@@ -33,7 +33,7 @@ class TPSSpatialTransformer(nn.Module):
         ys, xs_ = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
         coord = torch.stack([xs_.reshape(-1) / (W - 1), ys.reshape(-1) / (H - 1)], 1)
         rep = torch.cat([_partial_repr(coord, ctrl), torch.ones(H * W, 1), coord], 1)
-        self.register_buffer('inverse_kernel', torch.inverse(fk))
+        self.register_buffer('inverse_kernel', torch.inverse(fk).contiguous())
         self.register_buffer('padding_matrix', torch.zeros(3, 2))
         self.register_buffer('target_coordinate_repr', rep)
         self.register_buffer('target_control_points', ctrl)

@@ -1,0 +1,137 @@
+"""Training step of the SR generator on the HIP path (reference: interfaces/super_resolution_eng.py:214-279,
+restricted to BASELINE config 2: one SR forward/backward, ImageLoss.mean()*100, clip_grad_norm_ 0.25, Adam).
+
+Parameters and gradients live in two flat fp32 buffers laid out in the order the backward pass produces the
+gradients (tail -> SRBs -> TP interpreter -> block1/STN), so that data-parallel training all-reduces four
+contiguous buckets over RCCL while the rest of the backward pass is still running, and the fused
+clip+Adam kernel touches every parameter once.  Every nn.Parameter of the module stays a view of the flat
+buffer (state_dict / checkpoints are unaffected).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .lib import lib
+
+BUCKETS = ["tail", "srbs", "infogen", "head"]
+
+
+def _bucket_of(name: str, srb_nums: int) -> int:
+    blk = name.split(".")[0]
+    if blk in (f"block{srb_nums + 2}", f"block{srb_nums + 3}"):
+        return 0
+    if blk.startswith("block") and blk != "block1":
+        return 1
+    if blk == "infoGen":
+        return 2
+    return 3                                            # block1, stn_head
+
+
+class SRTrainer:
+    def __init__(self, model, lr=1e-3, betas=(0.5, 0.999), eps=1e-8, max_norm=0.25, loss_weight=(1.0, 1e-4),
+                 use_graph=False, distributed=None):
+        self.model, self.L = model, lib()
+        self.lr, self.betas, self.eps, self.max_norm, self.loss_weight = lr, betas, eps, max_norm, loss_weight
+        self.world = dist.get_world_size() if (distributed if distributed is not None else dist.is_initialized()) else 1
+        self.eng = model.engine()
+        named = list(model.named_parameters())
+        dev = named[0][1].device
+        if dev.type != "cuda":
+            raise RuntimeError("SRTrainer needs the model on a GPU")
+        order = sorted(range(len(named)), key=lambda i: (_bucket_of(named[i][0], model.srb_nums), -i if _bucket_of(named[i][0], model.srb_nums) == 1 else i))
+        offs, off, self.bucket_range = {}, 0, [[None, None] for _ in BUCKETS]
+        for i in order:
+            n, p = named[i]
+            b = _bucket_of(n, model.srb_nums)
+            if self.bucket_range[b][0] is None:
+                self.bucket_range[b][0] = off
+            offs[n] = off
+            off += (p.numel() + 63) // 64 * 64              # 256-byte aligned slots (vector loads in the kernels)
+            self.bucket_range[b][1] = off
+        self.n = off
+        self.flat_p = torch.zeros(off, device=dev)
+        self.flat_g = torch.zeros(off, device=dev)
+        self.m = torch.zeros(off, device=dev)
+        self.v = torch.zeros(off, device=dev)
+        self.state = torch.zeros(8, device=dev)
+        self.ws = torch.empty(1024, device=dev)
+        self.G = {}
+        for n, p in named:
+            sl = slice(offs[n], offs[n] + p.numel())
+            self.flat_p[sl].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[sl].view(p.shape)
+            self.G[n] = self.flat_g[sl].view(p.shape)
+            p.grad = self.G[n]
+        if self.world > 1:                                    # identical replicas: rank 0's initial weights + buffers
+            dist.broadcast(self.flat_p, 0)
+            for b in model.buffers():
+                dist.broadcast(b, 0)
+        self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.eng.seed_dev = self.seed_dev
+        self.use_graph = use_graph
+        self.graph = None
+        self.static = None
+        self.per = None
+        self.steps = 0
+
+    # ------------------------------------------------------------------------------------------------------
+    def _fwd_bwd(self, lr_img, hr_img, tp, overlap):
+        L, B = self.L, lr_img.shape[0]
+        self.flat_g.zero_()
+        L.seed_bump(self.seed_dev)
+        sr, ctx = self.eng.forward(lr_img, tp, True, 0)
+        per = torch.empty(B, device=sr.device)
+        L.image_loss_fwd(sr, hr_img, per, B, 4, sr.shape[2], sr.shape[3], self.loss_weight[0], self.loss_weight[1])
+        dsr = torch.empty_like(sr)
+        L.image_loss_bwd(sr, hr_img, None, 100.0 / B, dsr, B, 4, sr.shape[2], sr.shape[3], self.loss_weight[0], self.loss_weight[1])
+        works = []
+
+        def on_stage(name):
+            if overlap:
+                a, b = self.bucket_range[BUCKETS.index(name)]
+                works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.AVG, async_op=True))
+
+        self.eng.backward(ctx, dsr, self.G, on_stage=on_stage)
+        return per, works
+
+    def _update(self):
+        self.L.clip_adam(self.flat_p, self.flat_g, self.m, self.v, self.n, self.lr, self.betas[0], self.betas[1], self.eps,
+                         self.max_norm, self.state, self.ws)
+
+    def step(self, lr_img, hr_img, tp):
+        """One optimisation step; returns the per-sample ImageLoss [B] (device tensor, no host sync)."""
+        self.model.train()
+        hr_img = hr_img.contiguous().float()
+        if not self.use_graph:
+            per, works = self._fwd_bwd(lr_img, hr_img, tp, overlap=self.world > 1)
+            for w in works:
+                w.wait()
+            self._update()
+            self.steps += 1
+            return per
+        # hipGraph path: forward+backward (+ optimiser when single-GPU) captured once, replayed per step
+        if self.graph is None:
+            self.static = [lr_img.clone().contiguous(), hr_img.clone(), tp.clone()]
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):                       # warm-up outside capture (allocator, lazy module loads)
+                self._fwd_bwd(*self.static, overlap=False)
+            torch.cuda.current_stream().wait_stream(s)
+            self.seed_dev.zero_()
+            # the warm-up touched BatchNorm running stats: harmless for a benchmark, noted for training use
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.per, _ = self._fwd_bwd(*self.static, overlap=False)
+                if self.world == 1:
+                    self._update()
+        for dst, src in zip(self.static, (lr_img, hr_img, tp)):
+            dst.copy_(src)
+        self.graph.replay()
+        if self.world > 1:
+            works = [dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.AVG, async_op=True) for a, b in self.bucket_range]
+            for w in works:
+                w.wait()
+            self._update()
+        self.steps += 1
+        return self.per

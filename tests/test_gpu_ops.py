@@ -76,7 +76,8 @@ def test_gemm_nn_tn_splitk_batched():
 
 
 CONVS = [(2, 16, 64, 64, 64, 3), (2, 16, 64, 4, 64, 9), (1, 32, 128, 64, 4, 9), (3, 8, 32, 32, 64, 3),
-         (2, 1, 2, 256, 256, 3), (2, 16, 64, 64, 256, 3), (5, 2, 8, 128, 256, 3)]
+         (2, 1, 2, 256, 256, 3), (2, 16, 64, 64, 256, 3), (5, 2, 8, 128, 256, 3), (4, 2, 8, 128, 256, 3),
+         (4, 4, 16, 64, 128, 3), (4, 1, 4, 256, 256, 3)]
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k", CONVS)
@@ -104,7 +105,8 @@ def test_conv_fwd_dgrad_wgrad(B, H, W, Cin, Cout, k):
     close(db, b.grad, what="dbias")
 
 
-@pytest.mark.parametrize("R_,C,act", [(2048, 64, 2), (100, 32, 1), (4, 512, 1), (20000, 256, 0), (4, 256, 1)])
+@pytest.mark.parametrize("R_,C,act", [(2048, 64, 2), (100, 32, 1), (4, 512, 1), (20000, 256, 0), (4, 256, 1), (256, 128, 1),
+                                       (1024, 64, 1), (64, 256, 1), (16, 256, 1)])
 def test_batchnorm_train_fwd_bwd(R_, C, act):
     x = (rnd(R_, C) * 2 + 0.5).requires_grad_(True)
     g_, b_ = (1 + 0.2 * rnd(C, seed=1)).requires_grad_(True), rnd(C, seed=2).requires_grad_(True)
