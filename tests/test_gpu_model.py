@@ -59,7 +59,10 @@ def test_train_step_vs_reference_golden(K, B):
     m.dropout_p = 0.0                                     # parity is defined with dropout off (goldens too)
     hr, lr, tp = procgen.make_inputs(B, K, seed=0)
     sr = m(lr.cuda(), tp.cuda())
-    check_against(g, "sr", sr, STAGE_TOL, 1e-4)
+    # tight against the reference's fp64 run; loose against its fp32 run, whose own rounding noise (tiny-batch
+    # BatchNorm in the STN head, then x64 pixel scaling in grid_sample) is several times larger than ours
+    check_against(g, "f64/sr", sr, 2e-5, 5e-5)
+    check_against(g, "sr", sr, 2e-4, 5e-4)
     from tatt_amd.loss.image_loss import ImageLoss
     per = ImageLoss(gradient=True, loss_weight=[1, 1e-4])(sr, hr.cuda())
     np.testing.assert_allclose(per.detach().cpu().numpy(), g["image_loss"], rtol=5e-5)
@@ -80,7 +83,11 @@ def test_train_fwd_bwd_vs_oracle_with_stages(p):
     m = build(K, seed=1).train()
     hr, lr, tp = procgen.make_inputs(B, K, seed=2)
     sr, ctx = m.engine().forward(lr.cuda(), tp.cuda(), True, seed, p_drop=p)
-    P = leafify(state)
+    # the oracle runs in fp64 here: it is then the rounding-free statement of the reference algorithm (an fp32 CPU
+    # run of the same code is itself ~8e-3 off on the STN gradients, measured with tools/debug_grads.py)
+    P = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in leafify(state).items()}
+    P = {k: (v.detach().requires_grad_(True) if v.is_floating_point() and not is_buffer(k) else v) for k, v in P.items()}
+    lr, hr, tp = lr.double(), hr.double(), tp.double()
     inter = {}
     sr_o = R.tsrn_forward(P, lr, tp, training=True, drop=R.HashDropout(p, seed) if p > 0 else None, inter=inter)
     st = stages(ctx, B)
@@ -88,12 +95,12 @@ def test_train_fwd_bwd_vs_oracle_with_stages(p):
     assert rel_l2(ctrl.cpu().numpy(), inter["ctrl_points"].detach().numpy()) < 2e-5
     for k in ["block1", "query_pos", "memory", "tp_map", "block2", "block4", "block6", "pre_sigmoid"]:
         r = rel_l2(st[k].cpu().numpy(), inter[k].detach().numpy())
-        assert r < STAGE_TOL, f"{k}: {r:.3e}"
-    assert float((sr.cpu() - sr_o.detach()).abs().max()) < 1e-4
+        assert r < 2e-5, f"{k}: {r:.3e}"
+    assert float((sr.cpu() - sr_o.detach()).abs().max()) < 2e-5
     # backward through the HIP loss kernel and the engine
     L = m.engine().L
     dsr = torch.empty_like(sr)
-    L.image_loss_bwd(sr, hr.cuda(), None, 100.0 / B, dsr, B, 4, 32, 128, 1.0, 1e-4)
+    L.image_loss_bwd(sr, hr.float().cuda(), None, 100.0 / B, dsr, B, 4, 32, 128, 1.0, 1e-4)
     G = {n: torch.zeros_like(q) for n, q in m.named_parameters()}
     m.engine().backward(ctx, dsr, G)
     (R.image_loss(sr_o, hr).mean() * 100).backward()
@@ -106,7 +113,7 @@ def test_train_fwd_bwd_vs_oracle_with_stages(p):
             assert float(got.abs().max()) == 0.0, n
             continue
         err = (got.double() - ref.double()).norm().item()
-        if err > 2e-3 * ref.double().norm().item() + 2e-6 * tot:
+        if err > 1e-3 * ref.double().norm().item() + 1e-6 * tot:
             bad.append((n, err, ref.norm().item()))
     assert not bad, f"gradient mismatches vs oracle: {bad[:8]}"
 
