@@ -41,6 +41,10 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
  * (9x9 64->4) and model/stn_head.py:15.  Weights stay in the reference's OIHW layout; (w_sn,w_sci,w_base,
  * w_stap) describe how (cout, cin, tap) is addressed: forward (Cin*T, T, 0, 1); dgrad (T, Cin_f*T, T-1, -1). */
 int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu, hipStream_t stream);
+/* Cout in {4,8,16} (9x9 64->4 output conv model/tsrn.py:625 and the dgrad of the 9x9 4->64 conv :598): dense planar GEMM
+ * Z[(tap,co)][pixel] followed by a shifted gather-sum, instead of padding Cout to the 64-wide MFMA tile. */
+size_t tatt_conv_skinny_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW);
+int tatt_conv_skinny_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, float* workspace, hipStream_t stream);
 size_t tatt_conv_wgrad_workspace(int Cin, int Cout, int KH, int KW, int splitk);
 int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long lddy, int splitk, float* workspace, int accumulate, hipStream_t stream);
 

@@ -74,6 +74,24 @@ __device__ __forceinline__ float mish_gradf_(float x) {
   return t + x * (1.0f - t * t) * s;
 }
 
+// Second stage of the two-stage column reductions: a 256-thread block sums partial[b*stride_b + c] over b for
+// 16 columns (c = blockIdx.x*16 + (tid&15)) with 16 row lanes (tid>>4); the result is valid in the threads with
+// tid < 16.  red: 256 floats of LDS.  Keeps the reduction deterministic and ~16x shorter than one thread per column.
+__device__ __forceinline__ float block16_colsum(const float* __restrict__ partial, int nblk, long stride_b, int c, bool cvalid,
+                                                float* red) {
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  float s = 0.f;
+  if (cvalid)
+    for (int b = rl; b < nblk; b += 16) s += partial[(long)b * stride_b + c];
+  red[rl * 16 + cl] = s;
+  __syncthreads();
+  float t = 0.f;
+  if (rl == 0)
+    for (int j = 0; j < 16; ++j) t += red[j * 16 + cl];
+  __syncthreads();
+  return t;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

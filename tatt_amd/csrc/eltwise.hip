@@ -86,10 +86,10 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict_
   }
 }
 __global__ void colsum_final_k(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(long)b * C + c];
+  __shared__ float red[256];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  float s = block16_colsum(partial, nblk, (long)C, c, c < C, red);
+  if (threadIdx.x >= 16 || c >= C) return;
   out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -272,7 +272,7 @@ int tatt_colsum(const float* x, long ld, int R, int C, float* out, int accumulat
   // CT = min(C,256) must divide 256 for the row-lane split; otherwise fall back to one row lane
   hipLaunchKernelGGL(colsum_partial_k, dim3(nblk), dim3(256), 0, st, x, ld, R, C, rpb, workspace);
   TATT_LAUNCH_CHECK("colsum_partial");
-  hipLaunchKernelGGL(colsum_final_k, dim3(cdiv(C, 64)), dim3(64), 0, st, workspace, nblk, C, out, accumulate);
+  hipLaunchKernelGGL(colsum_final_k, dim3(cdiv(C, 16)), dim3(256), 0, st, workspace, nblk, C, out, accumulate);
   TATT_LAUNCH_CHECK("colsum_final");
   return TATT_OK;
 }

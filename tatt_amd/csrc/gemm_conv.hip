@@ -311,19 +311,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 // perm mode 0: identity over [M,N] with ldc; mode 1: conv weight (co, tap, ci) -> OIHW (co, ci, tap)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, float* __restrict__ dst,
                                      const float* __restrict__ bias, int M, int N, long ldc, int accumulate, int relu,
-                                     int perm, int Cin, int T) {
+                                     int perm, int Cin, int T, long dst_batch_stride) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)M * N) return;
-  float s = 0.f;
-  for (int z = 0; z < nslab; ++z) s += slabs[z * slab_stride + i];
+  // blockIdx.y = batch index: slabs [batch][nslab][M*N], dst advanced by dst_batch_stride
+  slabs += (long)blockIdx.y * nslab * slab_stride;
+  dst += (long)blockIdx.y * dst_batch_stride;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // independent chains so that the loads overlap
+  int z = 0;
+  for (; z + 4 <= nslab; z += 4) {
+    s0 += slabs[(z + 0) * slab_stride + i];
+    s1 += slabs[(z + 1) * slab_stride + i];
+    s2 += slabs[(z + 2) * slab_stride + i];
+    s3 += slabs[(z + 3) * slab_stride + i];
+  }
+  for (; z < nslab; ++z) s0 += slabs[z * slab_stride + i];
+  float s = (s0 + s1) + (s2 + s3);
   int m = (int)(i / N), n = (int)(i - (long)m * N);
   long o;
   if (perm == 1) {
     int tap = n / Cin, ci = n - tap * Cin;
     o = ((long)m * Cin + ci) * T + tap;
-  } else if (perm == 2) {  // m = (tap, ci), n = co
-    int tap = m / Cin, ci = m - tap * Cin;
-    o = ((long)n * Cin + ci) * T + tap;
+  } else if (perm == 3) {  // tiny-Cout wgrad, roles swapped: m = ci_f, n = (flipped tap, co_f); Cin here = Cout_f
+    int tapf = n / Cin, co = n - tapf * Cin;
+    o = ((long)co * M + m) * T + (T - 1 - tapf);
   } else {
     o = (long)m * ldc + n;
   }
@@ -331,6 +342,47 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_
   if (accumulate) s += dst[o];
   if (relu) s = fmaxf(s, 0.f);
   dst[o] = s;
+}
+
+// ---- skinny-Cout convolution (Cout <= 16: the 9x9 64->4 output conv and the 9x9 dgrad of block1) ----------------
+// A Cout of 4 would fill 1/16 of the 64-wide MFMA N tile.  Instead: Z[(tap,co)][pixel] = sum_ci Wr[(tap,co)][ci] * X[pixel][ci]
+// (a dense GEMM with M = T*Cout, K = Cin, planar output), then Y[p][co] = bias + sum_tap Z[(tap,co)][p + shift(tap)].
+__global__ void skinny_repack_w(const float* __restrict__ Wt, float* __restrict__ Wr, int Cin, int Cout, int T, long w_sn, long w_sci,
+                                long w_base, long w_stap) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;  // (tap, co, ci)
+  if (i >= T * Cout * Cin) return;
+  int ci = i % Cin, co = (i / Cin) % Cout, tap = i / (Cin * Cout);
+  Wr[i] = Wt[(long)co * w_sn + (long)ci * w_sci + w_base + (long)tap * w_stap];
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void skinny_gather(const float* __restrict__ Z, const float* __restrict__ bias,
+                                                     float* __restrict__ Y, int B, int H, int W, int KH, int KW, long ldy,
+                                                     int accumulate) {
+  const long P = (long)B * H * W;
+  long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int hw = H * W;
+  const int rem = (int)(p % hw);
+  const int y = rem / W, x = rem - y * W;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = bias ? bias[c] : 0.f;
+  for (int dy = 0; dy < KH; ++dy) {
+    const int yy = y + dy - KH / 2;
+    if (yy < 0 || yy >= H) continue;
+    for (int dx = 0; dx < KW; ++dx) {
+      const int xx = x + dx - KW / 2;
+      if (xx < 0 || xx >= W) continue;
+      const long q = p + (long)(dy - KH / 2) * W + (dx - KW / 2);
+      const float* zp = Z + (long)(dy * KW + dx) * COUT * P + q;
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) acc[c] += zp[(long)c * P];
+    }
+  }
+  float* dst = Y + p * ldy;
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) dst[c] = accumulate ? dst[c] + acc[c] : acc[c];
 }
 
 template <int AOP, int BOP>
@@ -352,7 +404,8 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
               long sbn, long sbk, long ldc, int batch, long sAb, long sBb, long sCb, int accumulate, int relu, int splitk,
               float* workspace, hipStream_t st) {
   TATT_CHECK_ARG(M > 0 && N > 0 && K >= 0 && batch > 0, "tatt_gemm: bad dims M=%d N=%d K=%d batch=%d", M, N, K, batch);
-  TATT_CHECK_ARG(splitk >= 1 && (splitk == 1 || (workspace && batch == 1)), "tatt_gemm: split-K needs workspace and batch==1");
+  TATT_CHECK_ARG(splitk >= 1 && (splitk == 1 || workspace), "tatt_gemm: split-K needs a workspace");
+  TATT_CHECK_ARG(splitk == 1 || batch == 1 || bias == nullptr, "tatt_gemm: batched split-K takes no bias");
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.B = B; a.C = C; a.bias = bias;
@@ -363,10 +416,11 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
   a.accumulate = accumulate; a.relu = relu;
   a.kchunk = cdiv(cdiv(K, splitk), BK) * BK;
   if (a.kchunk == 0) a.kchunk = BK;
-  if (splitk > 1) {
+  if (splitk > 1) {  // slabs [batch][splitk][M][N]
     a.C = workspace;
     a.ldc = N;
     a.sCz = (long)M * N;
+    a.sCb = (long)M * N * splitk;
   }
   const bool arow = (sam == 1 && sak != 1), brow = (sbn == 1 && sbk != 1);
   int rc;
@@ -377,8 +431,8 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
   if (rc) return rc;
   if (splitk > 1) {
     long tot = (long)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, workspace, (long)M * N, splitk, C, bias,
-                       M, N, ldc, accumulate, relu, 0, 0, 0);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256), batch), dim3(256), 0, st, workspace, (long)M * N, splitk, C, bias,
+                       M, N, ldc, accumulate, relu, 0, 0, 0, sCb);
     TATT_LAUNCH_CHECK("splitk_reduce");
   }
   return TATT_OK;
@@ -407,6 +461,42 @@ int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, 
   return launch<OP_IM2COL, OP_CONVW>(a, 1, st);
 }
 
+// Workspace floats of tatt_conv_skinny_fwd: planar Z [T*Cout][B*H*W] + repacked weights [T*Cout][Cin].
+size_t tatt_conv_skinny_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW) {
+  return (size_t)KH * KW * Cout * ((size_t)B * H * W + Cin) + 64;
+}
+
+// Same contract as tatt_conv_fwd (no relu) for Cout in {4, 8, 16}; see the kernels above.
+int tatt_conv_skinny_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH,
+                         int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate,
+                         float* workspace, hipStream_t st) {
+  TATT_CHECK_ARG(Cout == 4 || Cout == 8 || Cout == 16, "tatt_conv_skinny_fwd: Cout must be 4, 8 or 16 (got %d)", Cout);
+  TATT_CHECK_ARG(workspace && (KH & 1) && (KW & 1) && B > 0, "tatt_conv_skinny_fwd: bad arguments");
+  const int T = KH * KW;
+  const long P = (long)B * H * W;
+  TATT_CHECK_ARG(P < (1L << 31), "tatt_conv_skinny_fwd: too many pixels");
+  float* Wr = workspace;
+  float* Z = workspace + (((size_t)T * Cout * Cin + 63) / 64) * 64;
+  hipLaunchKernelGGL(skinny_repack_w, dim3(cdiv((long)T * Cout * Cin, 256)), dim3(256), 0, st, Wt, Wr, Cin, Cout, T, w_sn, w_sci, w_base,
+                     w_stap);
+  TATT_LAUNCH_CHECK("skinny_repack_w");
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = Wr; a.B = X; a.C = Z;
+  a.M = T * Cout; a.N = (int)P; a.K = Cin;
+  a.sam = Cin; a.sak = 1; a.sbn = ldx; a.sbk = 1; a.ldc = P;
+  a.splitk = 1;
+  a.kchunk = cdiv(Cin, BK) * BK;
+  int rc = launch<OP_STRIDED, OP_STRIDED>(a, 1, st);
+  if (rc) return rc;
+  dim3 grid(cdiv(P, 256));
+  if (Cout == 4) hipLaunchKernelGGL((skinny_gather<4>), grid, dim3(256), 0, st, Z, bias, Y, B, H, W, KH, KW, ldy, accumulate);
+  else if (Cout == 8) hipLaunchKernelGGL((skinny_gather<8>), grid, dim3(256), 0, st, Z, bias, Y, B, H, W, KH, KW, ldy, accumulate);
+  else hipLaunchKernelGGL((skinny_gather<16>), grid, dim3(256), 0, st, Z, bias, Y, B, H, W, KH, KW, ldy, accumulate);
+  TATT_LAUNCH_CHECK("skinny_gather");
+  return TATT_OK;
+}
+
 size_t tatt_conv_wgrad_workspace(int Cin, int Cout, int KH, int KW, int splitk) {
   return (size_t)Cout * KH * KW * Cin * (splitk > 0 ? splitk : 1);
 }
@@ -427,18 +517,21 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
   a.sCz = (long)a.M * a.N;
   a.kchunk = cdiv(cdiv(a.K, splitk), BK) * BK;
   a.g = ConvGeom{H, W, Cin, KH, KW, KH / 2, KW / 2, (int)ldx};
-  int perm = 1;
-  if (Cout <= 16) {
-    // tiny Cout (the 9x9 64->4 output conv): put (tap,ci) on the 128-wide M side, Cout on N
+  int perm = 1, perm_c = Cin;
+  if (Cout <= 16 && Cout % 4 == 0 && lddy % 4 == 0 && (((uintptr_t)dY) & 15) == 0) {
+    // tiny Cout (the 9x9 64->4 output conv): swap the roles of X and dY so that the wide tensor sits on the M side and
+    // the im2col runs over the 4-channel one:  D[ci][(tap',co)] = sum_q X[q][ci] * dY[q+shift(tap')][co]
+    //                                          = dW[co][ci][T-1-tap']   (undone by perm 3 in the reduce kernel)
     a.A = X; a.B = dY;
-    a.M = T * Cin; a.N = Cout;
-    a.sam = 0; a.sak = 0;
-    a.sbn = 1; a.sbk = lddy;
+    a.M = Cin; a.N = T * Cout;
+    a.sam = 1; a.sak = ldx;
     a.ldc = a.N;
     a.sCz = (long)a.M * a.N;
-    perm = 2;
+    a.g = ConvGeom{H, W, Cout, KH, KW, KH / 2, KW / 2, (int)lddy};
+    perm = 3;
+    perm_c = Cout;
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), splitk);
-    hipLaunchKernelGGL((gemm_kernel<OP_IM2COL_M, OP_ROWCONTIG>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemm_kernel<OP_ROWCONTIG, OP_IM2COL_N>), grid, dim3(256), 0, st, a);
   } else {
     // the kernel treats splitk>1 as "write raw slabs"; with splitk==1 it applies bias/accumulate (none set): same result.
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), splitk);
@@ -447,7 +540,7 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
   TATT_LAUNCH_CHECK("conv_wgrad");
   long tot = (long)a.M * a.N;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, workspace, tot, splitk, dW, (const float*)nullptr,
-                     a.M, a.N, (long)a.N, accumulate, 0, perm, Cin, T);
+                     a.M, a.N, (long)a.N, accumulate, 0, perm, perm_c, T, 0L);
   TATT_LAUNCH_CHECK("conv_wgrad_reduce");
   return TATT_OK;
 }

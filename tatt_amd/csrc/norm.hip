@@ -46,15 +46,30 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
 __global__ void bn_stats_final(const float* __restrict__ partial, int nblk, int R, int C, int rows_per_blk, float eps,
                                float momentum, float* __restrict__ stat, float* __restrict__ run_mean,
                                float* __restrict__ run_var) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  // block = 16 channels x 16 row lanes: each lane Chan-merges a strided subset of the row blocks, lane 0 merges the 16
+  __shared__ float sn[256], sm[256], s2[256];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int b = 0; b < nblk; ++b) {
-    float nb = (float)(min(R, (b + 1) * rows_per_blk) - b * rows_per_blk);
-    float mb = partial[((long)b * 2 + 0) * C + c], m2b = partial[((long)b * 2 + 1) * C + c];
-    float d = mb - mean, nn = n + nb;
+  if (c < C)
+    for (int b = rl; b < nblk; b += 16) {
+      float nb = (float)(min(R, (b + 1) * rows_per_blk) - b * rows_per_blk);
+      float mb = partial[((long)b * 2 + 0) * C + c], m2b = partial[((long)b * 2 + 1) * C + c];
+      float d = mb - mean, nn = n + nb;
+      mean += d * (nb / nn);
+      m2 += m2b + d * d * (n * nb / nn);
+      n = nn;
+    }
+  sn[threadIdx.x] = n; sm[threadIdx.x] = mean; s2[threadIdx.x] = m2;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  n = 0.f; mean = 0.f; m2 = 0.f;
+  for (int j = 0; j < 16; ++j) {
+    float nb = sn[j * 16 + cl];
+    if (nb == 0.f) continue;
+    float d = sm[j * 16 + cl] - mean, nn = n + nb;
     mean += d * (nb / nn);
-    m2 += m2b + d * d * (n * nb / nn);
+    m2 += s2[j * 16 + cl] + d * d * (n * nb / nn);
     n = nn;
   }
   float var = m2 / n;
@@ -145,13 +160,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ x
 // sums[2][C]; dgamma/dbeta (+)=
 __global__ void bn_bwd_final(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums,
                              float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int b = 0; b < nblk; ++b) {
-    s1 += partial[((long)b * 2 + 0) * C + c];
-    s2 += partial[((long)b * 2 + 1) * C + c];
-  }
+  __shared__ float red[256];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  float s1 = block16_colsum(partial, nblk, 2L * C, c, c < C, red);
+  float s2 = block16_colsum(partial + C, nblk, 2L * C, c, c < C, red);
+  if (threadIdx.x >= 16 || c >= C) return;
   sums[c] = s1;
   sums[C + c] = s2;
   if (dgamma) {
@@ -253,12 +266,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ v
 
 __global__ void ln_bwd_final(const float* __restrict__ partial, int nblk, float* __restrict__ dgamma, float* __restrict__ dbeta,
                              int accumulate) {
-  int c = threadIdx.x;
-  float a = 0.f, b = 0.f;
-  for (int k = 0; k < nblk; ++k) {
-    a += partial[((long)k * 2 + 0) * 64 + c];
-    b += partial[((long)k * 2 + 1) * 64 + c];
-  }
+  __shared__ float red[256];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  float a = block16_colsum(partial, nblk, 128L, c, true, red);
+  float b = block16_colsum(partial + 64, nblk, 128L, c, true, red);
+  if (threadIdx.x >= 16) return;
   dgamma[c] = accumulate ? dgamma[c] + a : a;
   dbeta[c] = accumulate ? dbeta[c] + b : b;
 }
@@ -283,7 +295,7 @@ int tatt_bn_stats(const float* x, long ldx, int R, int C, float eps, float momen
   bn_blocking(R, &nblk, &rpb);
   hipLaunchKernelGGL(bn_stats_partial, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, rpb, workspace);
   TATT_LAUNCH_CHECK("bn_stats_partial");
-  hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, 64)), dim3(64), 0, st, workspace, nblk, R, C, rpb, eps, momentum, stat, run_mean,
+  hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, 16)), dim3(256), 0, st, workspace, nblk, R, C, rpb, eps, momentum, stat, run_mean,
                      run_var);
   TATT_LAUNCH_CHECK("bn_stats_final");
   return TATT_OK;
@@ -314,7 +326,7 @@ int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const floa
   float* sums = workspace + (size_t)BN_MAXBLK * 2 * C;
   hipLaunchKernelGGL(bn_bwd_reduce, dim3(nblk), dim3(256), 0, st, x, ldx, dy, lddy, stat, gamma, beta, R, C, act, rpb, workspace);
   TATT_LAUNCH_CHECK("bn_bwd_reduce");
-  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 64)), dim3(64), 0, st, workspace, nblk, C, sums, dgamma, dbeta, accumulate_params);
+  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 16)), dim3(256), 0, st, workspace, nblk, C, sums, dgamma, dbeta, accumulate_params);
   TATT_LAUNCH_CHECK("bn_bwd_final");
   long tot = (long)R * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply, dim3(cdiv(tot, 256)), dim3(256), 0, st, x, ldx, dy, lddy, stat, gamma, beta, sums, dx, lddx, R, C,
@@ -346,7 +358,7 @@ int tatt_ln_bwd(const float* v, const float* dy, float dyscale, const float* gam
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, st, v, dy, dyscale, gamma, dv, dv_accumulate, dres, dc, workspace, rows,
                      rpb, eps);
   TATT_LAUNCH_CHECK("ln_bwd");
-  hipLaunchKernelGGL(ln_bwd_final, dim3(1), dim3(64), 0, st, workspace, nblk, dgamma, dbeta, accumulate_params);
+  hipLaunchKernelGGL(ln_bwd_final, dim3(4), dim3(256), 0, st, workspace, nblk, dgamma, dbeta, accumulate_params);
   TATT_LAUNCH_CHECK("ln_bwd_final");
   return TATT_OK;
 }

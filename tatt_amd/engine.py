@@ -105,13 +105,22 @@ class Engine:
     def colsum(self, x, R, C, out, ld=None):
         self.L.colsum(x, ld or C, R, C, out, 1, self.ws)
 
+    def _skinny(self, x, W, b, out, B, H, Wd, Cin, Cout, k, wstr, acc):
+        wsz = self.L.conv_skinny_workspace(B, H, Wd, Cin, Cout, k, k)
+        z = self.new(wsz)                                      # planar Z [(tap,co)][pixel]: 340 MB for the output conv at B=64
+        self.L.conv_skinny_fwd(x, W, b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout, *wstr, acc, z)
+
     def conv(self, x, W, b, out, B, H, Wd, Cin, Cout, k, acc=0, relu=0):
         T = k * k
+        if Cout in (4, 8, 16) and not relu:
+            return self._skinny(x, W, b, out, B, H, Wd, Cin, Cout, k, (Cin * T, T, 0, 1), acc)
         self.L.conv_fwd(x, W, b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout, Cin * T, T, 0, 1, acc, relu)
 
     def conv_dgrad(self, dy, W, dx, B, H, Wd, Cin, Cout, k, acc=0):
         """dx[B,H,W,Cin] (+)= conv^T(dy[B,H,W,Cout]);  W is the forward OIHW weight [Cout,Cin,k,k]."""
         T = k * k
+        if Cin in (4, 8, 16):
+            return self._skinny(dy, W, None, dx, B, H, Wd, Cout, Cin, k, (T, Cin * T, T - 1, -1), acc)
         self.L.conv_fwd(dy, W, None, dx, B, H, Wd, Cout, Cin, k, k, Cout, Cin, T, Cin * T, T - 1, -1, acc, 0)
 
     def conv_wgrad(self, x, dy, dW, db, B, H, Wd, Cin, Cout, k):
@@ -361,7 +370,8 @@ class Engine:
         wdiff = (whh_b.data_ptr() - whh_f.data_ptr()) // 4
         dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
         for s in range(B):
-            L.gemm(hstep[0, s], whh_f, gh_all[0, s], None, 64, 1536, 512, 512, 1, 512, 1, 1536, 2, dsh, wdiff, dsg, 0, 0, 1, None)
+            # [64,512] x [512,1536] per direction: split K 4 ways so that the step fills the chip (192 workgroups)
+            L.gemm(hstep[0, s], whh_f, gh_all[0, s], None, 64, 1536, 512, 512, 1, 512, 1, 1536, 2, dsh, wdiff, dsg, 0, 0, 4, self.ws)
             L.rpe_gate_fwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], hstep[0, s + 1], qp,
                            s, B, dsg, dsh)
         # encoder layer (input doubled, model/transformer_v2.py:273)
@@ -543,7 +553,7 @@ class Engine:
             L.rpe_gate_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
                            dgh_all[0, s], dgi_sum, s, B, dsg, dsh)
             if s > 0:
-                L.gemm(dgh_all[0, s], whh_f, carry, None, 64, 512, 1536, 1536, 1, 1, 512, 512, 2, dsg, wdiff, 64 * 512, 1, 0, 1, None)
+                L.gemm(dgh_all[0, s], whh_f, carry, None, 64, 512, 1536, 1536, 1, 1, 512, 512, 2, dsg, wdiff, 64 * 512, 1, 0, 8, self.ws)
         dxg = self.new(64, 1024)
         for dd, sfx in enumerate(["", "_reverse"]):
             self.linear_dw(dgh_all[dd], hstep[dd], G[g + "weight_hh_l0" + sfx], 64 * B, 1536, 512)

@@ -105,6 +105,37 @@ def test_conv_fwd_dgrad_wgrad(B, H, W, Cin, Cout, k):
     close(db, b.grad, what="dbias")
 
 
+@pytest.mark.parametrize("B,H,W,Cbig,Csmall,k", [(2, 32, 128, 64, 4, 9), (3, 16, 64, 64, 4, 9), (2, 8, 8, 32, 8, 3), (1, 5, 7, 64, 16, 3)])
+def test_conv_skinny_fwd_and_dgrad(B, H, W, Cbig, Csmall, k):
+    """Skinny-Cout path: forward Cbig->Csmall, and the dgrad of a Csmall->Cbig conv (model/tsrn.py:625, :598)."""
+    T = k * k
+    x = rnd(B, Cbig, H, W)
+    w = rnd(Csmall, Cbig, k, k, seed=1) / math.sqrt(Cbig * T)
+    b = rnd(Csmall, seed=2)
+    y = F.conv2d(x.double(), w.double(), b.double(), padding=k // 2)
+    wsz = L().conv_skinny_workspace(B, H, W, Cbig, Csmall, k, k)
+    out = torch.empty(B, H, W, Csmall, device="cuda")
+    L().conv_skinny_fwd(cu(x.permute(0, 2, 3, 1)), cu(w), cu(b), out, B, H, W, Cbig, Csmall, k, k, Cbig, Csmall, Cbig * T, T, 0, 1, 0, ws(wsz))
+    close(out.permute(0, 3, 1, 2), y, what="skinny fwd")
+    # dgrad of conv(Csmall -> Cbig): dx[Csmall] = conv^T(dy[Cbig])
+    xs = rnd(B, Csmall, H, W, seed=3).double().requires_grad_(True)
+    w2 = (rnd(Cbig, Csmall, k, k, seed=4) / math.sqrt(Csmall * T)).double()
+    dy = rnd(B, Cbig, H, W, seed=5)
+    F.conv2d(xs, w2, None, padding=k // 2).backward(dy.double())
+    dx = cu(torch.ones(B, H, W, Csmall))
+    L().conv_skinny_fwd(cu(dy.permute(0, 2, 3, 1)), cu(w2.float()), None, dx, B, H, W, Cbig, Csmall, k, k, Cbig, Csmall, T, Csmall * T,
+                        T - 1, -1, 1, ws(wsz))
+    close(dx.permute(0, 3, 1, 2), 1 + xs.grad, what="skinny dgrad (+accumulate)")
+
+
+def test_gemm_batched_splitk():
+    dgh, Wh = rnd(2, 64, 1536, seed=1) * 0.1, rnd(2, 1536, 512, seed=2) * 0.05
+    carry0 = rnd(2, 64, 512, seed=3)
+    carry = cu(carry0)
+    L().gemm(cu(dgh), cu(Wh), carry, None, 64, 512, 1536, 1536, 1, 1, 512, 512, 2, 64 * 1536, 1536 * 512, 64 * 512, 1, 0, 8, ws())
+    close(carry, carry0.double() + torch.einsum("bmk,bkn->bmn", dgh.double(), Wh.double()), what="batched split-K NN + accumulate")
+
+
 @pytest.mark.parametrize("R_,C,act", [(2048, 64, 2), (100, 32, 1), (4, 512, 1), (20000, 256, 0), (4, 256, 1), (256, 128, 1),
                                        (1024, 64, 1), (64, 256, 1), (16, 256, 1)])
 def test_batchnorm_train_fwd_bwd(R_, C, act):
