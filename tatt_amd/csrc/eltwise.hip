@@ -68,9 +68,44 @@ __global__ void sum_partials_k(const float* __restrict__ partial, int n, float s
 __global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict__ x, long ld, int R, int C, int rows_per_blk,
                                                         float* __restrict__ partial) {
   __shared__ float red[256];
-  const int CT = C < 256 ? C : 256, RL = 256 / CT;
-  const int tid = threadIdx.x, cl = tid % CT, rl = tid / CT;
+  const int tid = threadIdx.x;
   const int rb = blockIdx.x * rows_per_blk, re = min(R, rb + rows_per_blk);
+  if ((C & 3) == 0 && (ld & 3) == 0 && ((((uintptr_t)x) & 15) == 0) && C <= 1024) {
+    // vector path: thread = (float4 column group, row lane); two independent accumulators keep loads in flight
+    __shared__ float4 red4[256];
+    const int C4 = C >> 2, CT4 = C4 < 256 ? C4 : 256, RL4 = 256 / CT4;
+    const int cl4 = tid % CT4, rl4 = tid / CT4;
+    for (int c4 = cl4; c4 < C4; c4 += CT4) {
+      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+      if (rl4 < RL4) {
+        int r = rb + rl4;
+        for (; r + RL4 < re; r += 2 * RL4) {
+          float4 a = *reinterpret_cast<const float4*>(x + (long)r * ld + c4 * 4);
+          float4 b = *reinterpret_cast<const float4*>(x + (long)(r + RL4) * ld + c4 * 4);
+          s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+          s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (r < re) {
+          float4 a = *reinterpret_cast<const float4*>(x + (long)r * ld + c4 * 4);
+          s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+      }
+      red4[tid] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+      __syncthreads();
+      if (rl4 == 0) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < RL4; ++j) {
+          float4 v = red4[j * CT4 + cl4];
+          t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        *reinterpret_cast<float4*>(partial + (long)blockIdx.x * C + c4 * 4) = t;
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  const int CT = C < 256 ? C : 256, RL = 256 / CT;
+  const int cl = tid % CT, rl = tid / CT;
   for (int c = cl; c < C; c += CT) {
     float s = 0.f;
     if (rl < RL)

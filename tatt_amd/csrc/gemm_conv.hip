@@ -332,6 +332,9 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_
   if (perm == 1) {
     int tap = n / Cin, ci = n - tap * Cin;
     o = ((long)m * Cin + ci) * T + tap;
+  } else if (perm == 2) {  // wgrad with (tap,ci) on M: m = (tap, ci), n = co
+    int tap = m / Cin, ci = m - tap * Cin;
+    o = ((long)n * Cin + ci) * T + tap;
   } else if (perm == 3) {  // tiny-Cout wgrad, roles swapped: m = ci_f, n = (flipped tap, co_f); Cin here = Cout_f
     int tapf = n / Cin, co = n - tapf * Cin;
     o = ((long)co * M + m) * T + (T - 1 - tapf);
@@ -532,6 +535,18 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
     perm_c = Cout;
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), splitk);
     hipLaunchKernelGGL((gemm_kernel<OP_ROWCONTIG, OP_IM2COL_N>), grid, dim3(256), 0, st, a);
+  } else if (Cout <= 64 && lddy % 4 == 0 && (((uintptr_t)dY) & 15) == 0) {
+    // Cout <= 64 fits ONE 64-wide N tile: put (tap,ci) on the 128-wide M side so that no MFMA rows are padding
+    // (with Cout on M a 64-channel conv would fill only half of every 128-row tile).
+    a.A = X; a.B = dY;
+    a.M = T * Cin; a.N = Cout;
+    a.sam = 0; a.sak = 0;
+    a.sbn = 1; a.sbk = lddy;
+    a.ldc = a.N;
+    a.sCz = (long)a.M * a.N;
+    perm = 2;
+    dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), splitk);
+    hipLaunchKernelGGL((gemm_kernel<OP_IM2COL_M, OP_ROWCONTIG>), grid, dim3(256), 0, st, a);
   } else {
     // the kernel treats splitk>1 as "write raw slabs"; with splitk==1 it applies bias/accumulate (none set): same result.
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), splitk);

@@ -125,7 +125,12 @@ class Engine:
 
     def conv_wgrad(self, x, dy, dW, db, B, H, Wd, Cin, Cout, k):
         T = k * k
-        tiles = (-(-Cout // 128) * -(-(T * Cin) // 64)) if Cout > 16 else (-(-(T * Cin) // 128))
+        if Cout <= 16:                                         # roles swapped: M = Cin, N = T*Cout (see tatt_conv_wgrad)
+            tiles = -(-Cin // 128) * -(-(T * Cout) // 64)
+        elif Cout <= 64:                                       # M = T*Cin, N = Cout
+            tiles = -(-(T * Cin) // 128)
+        else:                                                  # M = Cout, N = T*Cin
+            tiles = -(-Cout // 128) * -(-(T * Cin) // 64)
         sk = max(1, min((B * H * Wd) // 256, -(-1024 // tiles)))
         while sk > 1 and Cout * T * Cin * sk > WS_FLOATS:
             sk //= 2
