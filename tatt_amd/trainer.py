@@ -28,6 +28,32 @@ def _bucket_of(name: str, srb_nums: int) -> int:
     return 3                                            # block1, stn_head
 
 
+def plan_flat_layout(named_shapes, srb_nums, align=64):
+    """Flat-buffer layout in gradient-production order.  named_shapes: [(name, numel)] in module order.
+    Returns (offsets {name: offset}, total floats, bucket_ranges [[begin, end]] per BUCKETS entry)."""
+    idx = list(range(len(named_shapes)))
+    bk = [_bucket_of(n, srb_nums) for n, _ in named_shapes]
+    order = sorted(idx, key=lambda i: (bk[i], -i if bk[i] == 1 else i))      # SRBs finish last-block-first
+    offs, off, ranges = {}, 0, [[None, None] for _ in BUCKETS]
+    for i in order:
+        n, numel = named_shapes[i]
+        if ranges[bk[i]][0] is None:
+            ranges[bk[i]][0] = off
+        offs[n] = off
+        off += (numel + align - 1) // align * align          # 256-byte aligned slots (vector loads in the kernels)
+        ranges[bk[i]][1] = off
+    return offs, off, ranges
+
+
+def allreduce_mean(t, async_op=False):
+    """Mean over ranks of a gradient bucket: AVG on RCCL; SUM + scale where AVG is not implemented (gloo on CPU)."""
+    if dist.get_backend() == "nccl":
+        return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=async_op)
+    w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=False)
+    t.div_(dist.get_world_size())
+    return None
+
+
 class SRTrainer:
     def __init__(self, model, lr=1e-3, betas=(0.5, 0.999), eps=1e-8, max_norm=0.25, loss_weight=(1.0, 1e-4),
                  use_graph=False, distributed=None):
@@ -39,16 +65,7 @@ class SRTrainer:
         dev = named[0][1].device
         if dev.type != "cuda":
             raise RuntimeError("SRTrainer needs the model on a GPU")
-        order = sorted(range(len(named)), key=lambda i: (_bucket_of(named[i][0], model.srb_nums), -i if _bucket_of(named[i][0], model.srb_nums) == 1 else i))
-        offs, off, self.bucket_range = {}, 0, [[None, None] for _ in BUCKETS]
-        for i in order:
-            n, p = named[i]
-            b = _bucket_of(n, model.srb_nums)
-            if self.bucket_range[b][0] is None:
-                self.bucket_range[b][0] = off
-            offs[n] = off
-            off += (p.numel() + 63) // 64 * 64              # 256-byte aligned slots (vector loads in the kernels)
-            self.bucket_range[b][1] = off
+        offs, off, self.bucket_range = plan_flat_layout([(n, p.numel()) for n, p in named], model.srb_nums)
         self.n = off
         self.flat_p = torch.zeros(off, device=dev)
         self.flat_g = torch.zeros(off, device=dev)
@@ -90,7 +107,7 @@ class SRTrainer:
         def on_stage(name):
             if overlap:
                 a, b = self.bucket_range[BUCKETS.index(name)]
-                works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.AVG, async_op=True))
+                works.append(allreduce_mean(self.flat_g[a:b], async_op=True))
 
         self.eng.backward(ctx, dsr, self.G, on_stage=on_stage)
         return per, works
@@ -106,7 +123,8 @@ class SRTrainer:
         if not self.use_graph:
             per, works = self._fwd_bwd(lr_img, hr_img, tp, overlap=self.world > 1)
             for w in works:
-                w.wait()
+                if w is not None:
+                    w.wait()
             self._update()
             self.steps += 1
             return per
@@ -129,9 +147,10 @@ class SRTrainer:
             dst.copy_(src)
         self.graph.replay()
         if self.world > 1:
-            works = [dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.AVG, async_op=True) for a, b in self.bucket_range]
+            works = [allreduce_mean(self.flat_g[a:b], async_op=True) for a, b in self.bucket_range]
             for w in works:
-                w.wait()
+                if w is not None:
+                    w.wait()
             self._update()
         self.steps += 1
         return self.per
