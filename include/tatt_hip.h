@@ -36,6 +36,11 @@ int tatt_version(void);
 size_t tatt_gemm_workspace(int M, int N, int splitk);
 int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int batch, long sAb, long sBb, long sCb, int accumulate, int relu, int splitk, float* workspace, hipStream_t stream);
 
+/* Weight + bias gradient of a Linear / 1x1 conv with a small output (M <= 96, N <= 64): dW[M,N] += dY[R,M]^T X[R,N],
+ * db[M] += colsum(dY) in ONE streaming pass over the R rows (autograd of F.linear at the sites above). */
+size_t tatt_tn_small_workspace(int M, int N);
+int tatt_tn_small(const float* dY, long lddy, const float* X, long ldx, float* dW, long lddw, float* db, int M, int N, int R, float* workspace, hipStream_t stream);
+
 /* ---- NHWC implicit-GEMM convolution (stride 1, "same" zero padding), fwd / dgrad / wgrad -------------------
  * Replaces nn.Conv2d at model/tsrn.py:598 (9x9 4->64), :868,:876 (SRB 3x3), :614, :1034 (64->256), :625
  * (9x9 64->4) and model/stn_head.py:15.  Weights stay in the reference's OIHW layout; (w_sn,w_sci,w_base,

@@ -64,13 +64,20 @@ __device__ __forceinline__ uint32_t tatt_eff_seed(const DropCfg& dc) {
   return dc.seed_dev ? dc.seed_site + dc.seed_dev[0] * 0x85EBCA77u : dc.seed_site;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
-__device__ __forceinline__ float mishf_(float x) { return x * tanhf(softplusf_(x)); }
+// Activations on the hardware exponential (v_exp_f32, ~1 ulp): one exp each instead of libm's tanhf/log1pf chains.
+//   tanh(softplus(x)) = (n^2 + 2n) / (n^2 + 2n + 2) with n = e^x   (exact identity; saturates to 1 for large x)
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
+__device__ __forceinline__ float tanh_softplus_(float x) {
+  if (x > 20.0f) return 1.0f;
+  float n = __expf(x);
+  float t = n * (n + 2.0f);
+  return t / (t + 2.0f);
+}
+__device__ __forceinline__ float mishf_(float x) { return x * tanh_softplus_(x); }
 __device__ __forceinline__ float mish_gradf_(float x) {
-  float sp = softplusf_(x);
-  float t = tanhf(sp);
-  float s = 1.0f / (1.0f + expf(-x));
+  float t = tanh_softplus_(x);
+  float s = sigmoidf_(x);
   return t + x * (1.0f - t * t) * s;
 }
 

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, c
       an += wn[k4 * 4] * hv.x + wn[k4 * 4 + 1] * hv.y + wn[k4 * 4 + 2] * hv.z + wn[k4 * 4 + 3] * hv.w;
     }
     float r = sigmoidf_(g_r + ar), z = sigmoidf_(g_z + az);
-    float n = tanhf(g_n + r * an);
+    float n = tanhf_(g_n + r * an);
     h = (1.f - z) * n + z * h;
     __builtin_amdgcn_wave_barrier();
     hbuf[slot][j] = h;
@@ -159,7 +159,7 @@ __global__ void rpe_gate_fwd(const float* __restrict__ gi, const float* __restri
   float hp = hprev[dir * dir_stride_h + (long)w * RH + j];
   float r = sigmoidf_(g_i[j] + g_h[j] + bh[j]);
   float z = sigmoidf_(g_i[RH + j] + g_h[RH + j] + bh[RH + j]);
-  float n = tanhf(g_i[2 * RH + j] + r * (g_h[2 * RH + j] + bh[2 * RH + j]));
+  float n = tanhf_(g_i[2 * RH + j] + r * (g_h[2 * RH + j] + bh[2 * RH + j]));
   float h = (1.f - z) * n + z * hp;
   hout[dir * dir_stride_h + (long)w * RH + j] = h;
   int tt = dir ? B - 1 - s : s;
@@ -181,7 +181,7 @@ __global__ void rpe_gate_bwd(const float* __restrict__ gi, const float* __restri
   float ghn = g_h[2 * RH + j] + bh[2 * RH + j];
   float r = sigmoidf_(g_i[j] + g_h[j] + bh[j]);
   float z = sigmoidf_(g_i[RH + j] + g_h[RH + j] + bh[RH + j]);
-  float n = tanhf(g_i[2 * RH + j] + r * ghn);
+  float n = tanhf_(g_i[2 * RH + j] + r * ghn);
   int tt = dir ? B - 1 - s : s;
   int f = dir * RH + j;
   long ci = ((long)dir * RW + w) * RH + j;

@@ -10,10 +10,55 @@ constexpr int BN_MAXBLK = 256;
 __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, long ldx, int R, int C, int rows_per_blk,
                                                         float* __restrict__ partial) {
   __shared__ float red[256];
-  const int CT = C < 256 ? C : 256, RL = 256 / CT;
-  const int tid = threadIdx.x, cl = tid % CT, rl = tid / CT;
+  const int tid = threadIdx.x;
   const int rb = blockIdx.x * rows_per_blk, re = min(R, rb + rows_per_blk);
   const int cnt = re - rb;
+  if ((C & 3) == 0 && (ldx & 3) == 0 && ((((uintptr_t)x) & 15) == 0) && C <= 1024) {
+    // vector path: thread = (float4 channel group, row lane); second pass re-reads the block's rows (L2 resident)
+    __shared__ float4 red4[256];
+    const int C4 = C >> 2, RL4 = 256 / C4;
+    const int cl4 = tid % C4, rl4 = tid / C4;
+    const bool on = rl4 < RL4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on)
+      for (int r = rb + rl4; r < re; r += RL4) {
+        float4 a = *reinterpret_cast<const float4*>(x + (long)r * ldx + cl4 * 4);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      }
+    red4[tid] = s;
+    __syncthreads();
+    float4 mean = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) {
+      for (int j = 0; j < RL4; ++j) {
+        float4 v = red4[j * C4 + cl4];
+        mean.x += v.x; mean.y += v.y; mean.z += v.z; mean.w += v.w;
+      }
+      const float ic = 1.f / (float)cnt;
+      mean.x *= ic; mean.y *= ic; mean.z *= ic; mean.w *= ic;
+    }
+    __syncthreads();
+    float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on)
+      for (int r = rb + rl4; r < re; r += RL4) {
+        float4 a = *reinterpret_cast<const float4*>(x + (long)r * ldx + cl4 * 4);
+        float dx = a.x - mean.x, dy = a.y - mean.y, dz = a.z - mean.z, dw = a.w - mean.w;
+        m2.x += dx * dx; m2.y += dy * dy; m2.z += dz * dz; m2.w += dw * dw;
+      }
+    red4[tid] = m2;
+    __syncthreads();
+    if (on && rl4 == 0) {
+      float4 t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < RL4; ++j) {
+        float4 v = red4[j * C4 + cl4];
+        t2.x += v.x; t2.y += v.y; t2.z += v.z; t2.w += v.w;
+      }
+      *reinterpret_cast<float4*>(partial + ((long)blockIdx.x * 2 + 0) * C + cl4 * 4) = mean;
+      *reinterpret_cast<float4*>(partial + ((long)blockIdx.x * 2 + 1) * C + cl4 * 4) = t2;
+    }
+    return;
+  }
+  const int CT = C < 256 ? C : 256, RL = 256 / CT;
+  const int cl = tid % CT, rl = tid / CT;
   for (int c = cl; c < C; c += CT) {
     float s = 0.f;
     if (rl < RL)
@@ -127,9 +172,50 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ x
                                                      const float* __restrict__ beta, int R, int C, int act, int rows_per_blk,
                                                      float* __restrict__ partial) {
   __shared__ float red[2][256];
-  const int CT = C < 256 ? C : 256, RL = 256 / CT;
-  const int tid = threadIdx.x, cl = tid % CT, rl = tid / CT;
+  const int tid = threadIdx.x;
   const int rb = blockIdx.x * rows_per_blk, re = min(R, rb + rows_per_blk);
+  if ((C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0) && C <= 1024) {
+    __shared__ float4 r1[256], r2[256];
+    const int C4 = C >> 2, RL4 = 256 / C4;
+    const int cl4 = tid % C4, rl4 = tid / C4;
+    const bool on = rl4 < RL4;
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (on) {
+      float mean[4], inv[4], ga[4], be[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mean[e] = stat[cl4 * 4 + e]; inv[e] = stat[C + cl4 * 4 + e]; ga[e] = gamma[cl4 * 4 + e]; be[e] = beta[cl4 * 4 + e];
+      }
+      for (int r = rb + rl4; r < re; r += RL4) {
+        float4 xv = *reinterpret_cast<const float4*>(x + (long)r * ldx + cl4 * 4);
+        float4 gv = *reinterpret_cast<const float4*>(dy + (long)r * lddy + cl4 * 4);
+        float xi[4] = {xv.x, xv.y, xv.z, xv.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xh = (xi[e] - mean[e]) * inv[e];
+          float g = gi[e] * act_grad(xh * ga[e] + be[e], act);
+          a1[e] += g;
+          a2[e] += g * xh;
+        }
+      }
+    }
+    r1[tid] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+    r2[tid] = make_float4(a2[0], a2[1], a2[2], a2[3]);
+    __syncthreads();
+    if (on && rl4 == 0) {
+      float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+      for (int j = 0; j < RL4; ++j) {
+        float4 u = r1[j * C4 + cl4], v = r2[j * C4 + cl4];
+        t1.x += u.x; t1.y += u.y; t1.z += u.z; t1.w += u.w;
+        t2.x += v.x; t2.y += v.y; t2.z += v.z; t2.w += v.w;
+      }
+      *reinterpret_cast<float4*>(partial + ((long)blockIdx.x * 2 + 0) * C + cl4 * 4) = t1;
+      *reinterpret_cast<float4*>(partial + ((long)blockIdx.x * 2 + 1) * C + cl4 * 4) = t2;
+    }
+    return;
+  }
+  const int CT = C < 256 ? C : 256, RL = 256 / CT;
+  const int cl = tid % CT, rl = tid / CT;
   for (int c = cl; c < C; c += CT) {
     float s1 = 0.f, s2 = 0.f;
     if (rl < RL) {

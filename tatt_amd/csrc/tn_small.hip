@@ -1,0 +1,138 @@
+// dW[M,N] (+)= dY[R,M]^T * X[R,N]  and  db[M] (+)= column sums of dY, for the many weight gradients whose output is
+// tiny (M <= 96, N <= 64) and whose reduction runs over all R = B*H*W rows: an HBM-bound streaming reduction.
+// No LDS staging: for v_mfma_f32_32x32x2_f32 lane (i = l&31, h = l>>5) supplies A[i][k=h] and B[k=h][i], which for row-major
+// [R, C] operands is exactly "lanes 0-31 read 32 consecutive floats of row r, lanes 32-63 of row r+1": coalesced 128-B
+// loads straight into the MFMA operands.  Each wave streams its own row range (deep unroll keeps loads in flight), the
+// four waves of a block are summed through LDS, every block writes one partial slab, a second kernel sums the slabs
+// in a fixed order (deterministic; no atomics).  The bias gradient rides along on the already loaded dY fragments.
+#include "common.h"
+
+namespace {
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void tn_small_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx,
+                                                       int M, int N, int R, int rows_per_blk, float* __restrict__ slabs) {
+  __shared__ float red[MT * 32 * NT * 32 + MT * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int rb = blockIdx.x * rows_per_blk, re = min(R, rb + rows_per_blk);
+  const int rows_per_wave = ((rows_per_blk + 7) / 8) * 2;  // even
+  const int r0 = rb + wave * rows_per_wave, r1 = min(re, r0 + rows_per_wave);
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  float asum[MT];
+  bool mok[MT], nok[NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    asum[a] = 0.f;
+    mok[a] = a * 32 + li < M;
+  }
+#pragma unroll
+  for (int b = 0; b < NT; ++b) nok[b] = b * 32 + li < N;
+
+  constexpr int U = (MT * NT >= 6) ? 4 : 8;  // k-pairs in flight (bounded by the VGPR budget of the 3x2 variant)
+  for (int r = r0; r < r1; r += 2 * U) {
+    float av[U][MT], bv[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = r + 2 * u + lh;
+      const bool rok = row < r1;
+#pragma unroll
+      for (int a = 0; a < MT; ++a) av[u][a] = (rok && mok[a]) ? dY[(long)row * lddy + a * 32 + li] : 0.f;
+#pragma unroll
+      for (int b = 0; b < NT; ++b) bv[u][b] = (rok && nok[b]) ? X[(long)row * ldx + b * 32 + li] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        asum[a] += av[u][a];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+      }
+    }
+  }
+  // ---- sum the four waves through LDS (wave 3 stores, 2..0 add), then wave 0 writes the block's slab ----
+  constexpr int NW = NT * 32;
+  float* cs = red + MT * 32 * NW;
+#pragma unroll
+  for (int a = 0; a < MT; ++a) asum[a] += __shfl_xor(asum[a], 32, 64);
+  for (int w = 3; w >= 0; --w) {
+    if (wave == w) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, n = b * 32 + li;
+            float v = acc[a][b][e];
+            if (w != 3) v += red[m * NW + n];
+            red[m * NW + n] = v;
+          }
+        if (lh == 0) {
+          float v = asum[a];
+          if (w != 3) v += cs[a * 32 + li];
+          cs[a * 32 + li] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = slabs + (long)blockIdx.x * (M * N + M);
+  for (int i = tid; i < M * N; i += 256) slab[i] = red[(i / N) * NW + (i % N)];
+  for (int i = tid; i < M; i += 256) slab[M * N + i] = cs[i];
+}
+
+// dW[m*lddw + n] += sum_blk slab[blk][m*N+n] ; db[m] += sum_blk slab[blk][M*N+m]
+__global__ void tn_small_reduce(const float* __restrict__ slabs, int nblk, int M, int N, float* __restrict__ dW, long lddw,
+                                float* __restrict__ db) {
+  // 16 outputs x 16 slab lanes per block (a thread per output would serialise nblk dependent L2 round trips)
+  __shared__ float red[256];
+  const int per = M * N + M;
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+  const float s = block16_colsum(slabs, nblk, (long)per, i, i < per, red);
+  if (threadIdx.x >= 16 || i >= per) return;
+  if (i < M * N) {
+    dW[(long)(i / N) * lddw + (i % N)] += s;
+  } else if (db) {
+    db[i - M * N] += s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t tatt_tn_small_workspace(int M, int N) { return (size_t)512 * ((size_t)M * N + M); }
+
+// dW[M,N] (row stride lddw) += dY[R,M]^T X[R,N];  db[M] += colsum(dY) (db may be null).  M <= 96, N <= 64.
+int tatt_tn_small(const float* dY, long lddy, const float* X, long ldx, float* dW, long lddw, float* db, int M, int N, int R,
+                  float* workspace, hipStream_t st) {
+  TATT_CHECK_ARG(M > 0 && N > 0 && R > 0 && M <= 96 && N <= 64 && workspace, "tatt_tn_small: need 0 < M <= 96, 0 < N <= 64 (got %d, %d)", M, N);
+  int nblk = (R + 127) / 128;
+  if (nblk > 512) nblk = 512;  // two blocks per CU: enough loads in flight to stream near the HBM rate
+  int rpb = ((R + nblk - 1) / nblk + 7) / 8 * 8;
+  nblk = (R + rpb - 1) / rpb;
+  const int MT = (M + 31) / 32, NT = (N + 31) / 32;
+#define TN_LAUNCH(a, b) hipLaunchKernelGGL((tn_small_kernel<a, b>), dim3(nblk), dim3(256), 0, st, dY, lddy, X, ldx, M, N, R, rpb, workspace)
+  if (MT == 1 && NT == 1) TN_LAUNCH(1, 1);
+  else if (MT == 1 && NT == 2) TN_LAUNCH(1, 2);
+  else if (MT == 2 && NT == 1) TN_LAUNCH(2, 1);
+  else if (MT == 2 && NT == 2) TN_LAUNCH(2, 2);
+  else if (MT == 3 && NT == 1) TN_LAUNCH(3, 1);
+  else TN_LAUNCH(3, 2);
+#undef TN_LAUNCH
+  TATT_LAUNCH_CHECK("tn_small_kernel");
+  const int per = M * N + M;
+  hipLaunchKernelGGL(tn_small_reduce, dim3(cdiv(per, 16)), dim3(256), 0, st, workspace, nblk, M, N, dW, lddw, db);
+  TATT_LAUNCH_CHECK("tn_small_reduce");
+  return TATT_OK;
+}
+
+}  // extern "C"

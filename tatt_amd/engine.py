@@ -102,6 +102,15 @@ class Engine:
         self.L.gemm(dy, x, dW, None, N, K, R, 1, lddy or N, 1, ldx or K, lddw or K, 1, 0, 0, 0, 1, 0, sk,
                     self.ws if sk > 1 else None)
 
+    def linear_dwb(self, dy, x, dW, db, R, N, K, lddy=None, ldx=None, lddw=None):
+        """dW[N,K] += dy^T x and db[N] += colsum(dy): one streaming pass (tatt_tn_small) when the output is small."""
+        if N <= 96 and K <= 64:
+            self.L.tn_small(dy, lddy or N, x, ldx or K, dW, lddw or K, db, N, K, R, self.ws)
+            return
+        self.linear_dw(dy, x, dW, R, N, K, lddy=lddy, ldx=ldx, lddw=lddw)
+        if db is not None:
+            self.colsum(dy, R, N, db, ld=lddy)
+
     def colsum(self, x, R, C, out, ld=None):
         self.L.colsum(x, ld or C, R, C, out, 1, self.ws)
 
@@ -197,16 +206,13 @@ class Engine:
         dg_in = self.new(R, 64)
         for d, sfx in enumerate(["", "_reverse"]):
             gi_d, gh_d, hp_d = dgi.view(-1)[96 * d:], dgh.view(-1)[96 * d:], hprev.view(-1)[32 * d:]
-            self.linear_dw(gh_d, hp_d, G[pre + "gru.weight_hh_l0" + sfx], R, 96, 32, lddy=192, ldx=64)
-            self.colsum(gh_d, R, 96, G[pre + "gru.bias_hh_l0" + sfx], ld=192)
-            self.linear_dw(gi_d, g_in, G[pre + "gru.weight_ih_l0" + sfx], R, 96, 64, lddy=192)
-            self.colsum(gi_d, R, 96, G[pre + "gru.bias_ih_l0" + sfx], ld=192)
+            self.linear_dwb(gh_d, hp_d, G[pre + "gru.weight_hh_l0" + sfx], G[pre + "gru.bias_hh_l0" + sfx], R, 96, 32, lddy=192, ldx=64)
+            self.linear_dwb(gi_d, g_in, G[pre + "gru.weight_ih_l0" + sfx], G[pre + "gru.bias_ih_l0" + sfx], R, 96, 64, lddy=192)
             self.linear_dx(gi_d, P[pre + "gru.weight_ih_l0" + sfx], dg_in, R, 96, 64, lddy=192, acc=d)
         Wc, dWc = P[pre + "conv1.weight"], G[pre + "conv1.weight"]
         Ktot = Wc.shape[1]
-        self.colsum(dg_in, R, 64, G[pre + "conv1.bias"])
-        for (x, off, kc, dx, acc) in inputs:
-            self.linear_dw(dg_in, x, dWc.view(-1)[off:], R, 64, kc, lddw=Ktot)
+        for i, (x, off, kc, dx, acc) in enumerate(inputs):
+            self.linear_dwb(dg_in, x, dWc.view(-1)[off:], G[pre + "conv1.bias"] if i == 0 else None, R, 64, kc, lddw=Ktot)
             if dx is not None:
                 self.linear_dx(dg_in, Wc.view(-1)[off:], dx, R, 64, kc, ldw=Ktot, acc=acc)
 
@@ -232,15 +238,13 @@ class Engine:
         Rq, Rk = B * Lq, B * 26
         W = P[pre + "in_proj_weight"]
         dW, db = G[pre + "in_proj_weight"], G[pre + "in_proj_bias"]
-        self.linear_dw(da, c, G[pre + "out_proj.weight"], Rq, 64, 64)
-        self.colsum(da, Rq, 64, G[pre + "out_proj.bias"])
+        self.linear_dwb(da, c, G[pre + "out_proj.weight"], G[pre + "out_proj.bias"], Rq, 64, 64)
         dc = self.new(Rq, 64)
         self.linear_dx(da, P[pre + "out_proj.weight"], dc, Rq, 64, 64)
         dQ, dK, dV = self.new(Rq, 64), self.new(Rk, 64), self.new(Rk, 64)
         self.L.attn_bwd(Q, K, V, dc, dQ, dK, dV, B, Lq, 26, *cfg, 0)
         for i, (d, x, R, dx, acc) in enumerate([(dQ, q_in, Rq, dq_in, acc_q), (dK, k_in, Rk, dk_in, acc_k), (dV, v_in, Rk, dv_in, acc_v)]):
-            self.linear_dw(d, x, dW[64 * i:], R, 64, 64)
-            self.colsum(d, R, 64, db[64 * i:])
+            self.linear_dwb(d, x, dW[64 * i:], db[64 * i:], R, 64, 64)
             if dx is not None:
                 self.linear_dx(d, W[64 * i:], dx, R, 64, 64, acc=acc)
 
@@ -260,13 +264,11 @@ class Engine:
         """dx += d/dx of linear2(drop(relu(linear1 x)))"""
         P = self.P
         h, hd = saved
-        self.linear_dw(df, hd, G[pre + "linear2.weight"], R, 64, 64)
-        self.colsum(df, R, 64, G[pre + "linear2.bias"])
+        self.linear_dwb(df, hd, G[pre + "linear2.weight"], G[pre + "linear2.bias"], R, 64, 64)
         dh = self.new(R, 64)
         self.linear_dx(df, P[pre + "linear2.weight"], dh, R, 64, 64)
         self.L.relu_drop_bwd(h, dh, dh, R * 64, *cfg)
-        self.linear_dw(dh, x, G[pre + "linear1.weight"], R, 64, 64)
-        self.colsum(dh, R, 64, G[pre + "linear1.bias"])
+        self.linear_dwb(dh, x, G[pre + "linear1.weight"], G[pre + "linear1.bias"], R, 64, 64)
         self.linear_dx(dh, P[pre + "linear1.weight"], dx, R, 64, 64, acc=1)
 
     def ln_fwd(self, pre, x, res, cfg, R, save_v=True):
@@ -544,8 +546,7 @@ class Engine:
         L.axpby(dsrc2, 2.0, None, 0.0, dt, Rt * 64, 0)
         dt0 = self.new(Rt, 64)
         L.prelu_bwd(t0, P[ig + "activation.weight"], dt, dt0, G[ig + "activation.weight"], 1, Rt * 64, self.ws)
-        self.linear_dw(dt0, tpr, G[ig + "fc_in.weight"], Rt, 64, K)
-        self.colsum(dt0, Rt, 64, G[ig + "fc_in.bias"])
+        self.linear_dwb(dt0, tpr, G[ig + "fc_in.weight"], G[ig + "fc_in.bias"], Rt, 64, K)
         # recurrent positional encoding, BPTT over the batch axis
         g = tr + "gru_encoding."
         whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]

@@ -128,6 +128,19 @@ def test_conv_skinny_fwd_and_dgrad(B, H, W, Cbig, Csmall, k):
     close(dx.permute(0, 3, 1, 2), 1 + xs.grad, what="skinny dgrad (+accumulate)")
 
 
+@pytest.mark.parametrize("R_,M,N,lddy,ldx", [(65536, 64, 64, 64, 64), (4100, 96, 32, 192, 64), (1664, 64, 37, 64, 37), (52, 96, 64, 192, 64),
+                                             (3000, 64, 64, 64, 128), (7, 40, 20, 40, 20)])
+def test_tn_small_dw_and_bias(R_, M, N, lddy, ldx):
+    dy, x = rnd(R_, lddy), rnd(R_, ldx, seed=1)
+    dW0, db0 = rnd(M, N + 3, seed=2), rnd(M, seed=3)
+    dW, db = cu(dW0), cu(db0)
+    L().tn_small(cu(dy), lddy, cu(x), ldx, dW, N + 3, db, M, N, R_, ws())
+    ref = dW0.double().clone()
+    ref[:, :N] += dy[:, :M].double().t() @ x[:, :N].double()
+    close(dW, ref, what="tn_small dW")
+    close(db, db0.double() + dy[:, :M].double().sum(0), 1e-5 if R_ < 60000 else 1e-4, "tn_small db")
+
+
 def test_gemm_batched_splitk():
     dgh, Wh = rnd(2, 64, 1536, seed=1) * 0.1, rnd(2, 1536, 512, seed=2) * 0.05
     carry0 = rnd(2, 64, 512, seed=3)
