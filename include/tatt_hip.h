@@ -46,6 +46,10 @@ int tatt_tn_small(const float* dY, long lddy, const float* X, long ldx, float* d
  * (9x9 64->4) and model/stn_head.py:15.  Weights stay in the reference's OIHW layout; (w_sn,w_sci,w_base,
  * w_stap) describe how (cout, cin, tap) is addressed: forward (Cin*T, T, 0, 1); dgrad (T, Cin_f*T, T-1, -1). */
 int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu, hipStream_t stream);
+/* Per-step weight repack for tatt_conv_fwd (same nn.Conv2d weights as above): Wf[co][tap][ci] for the forward pass,
+ * strides (T*Cin, 1, 0, Cin), and Wd[ci][tap][co] with the taps already flipped for dgrad, strides (T*Cout, 1, 0, Cout):
+ * the kernel's weight-tile loads become 16-byte contiguous instead of stride-T gathers. */
+int tatt_conv_pack_w(const float* Wt, float* Wf, float* Wd, int Cout, int Cin, int KH, int KW, hipStream_t stream);
 /* Cout in {4,8,16} (9x9 64->4 output conv model/tsrn.py:625 and the dgrad of the 9x9 4->64 conv :598): dense planar GEMM
  * Z[(tap,co)][pixel] followed by a shifted gather-sum, instead of padding Cout to the 64-wide MFMA tile. */
 size_t tatt_conv_skinny_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW);

@@ -2,21 +2,23 @@
 //   * tatt_gemm        : C[m,n] = sum_k A(m,k) B(n,k) (+bias, +C, relu), generic strides, batched, split-K
 //   * tatt_conv_fwd    : NHWC implicit-GEMM convolution (also used for dgrad with swapped/flipped weight strides)
 //   * tatt_conv_wgrad  : dW = dY^T * im2col(X), split-K over pixels into slabs
-// Tile: 128(M) x 64(N) x 32(K), 256 threads = 4 waves, each wave a 32x64 strip (two 32x32 accumulators).
-// LDS images are padded so that fragment reads are conflict free (row stride 36 floats for k-contiguous
-// images read with ds_read_b128; 132/68 floats for row-contiguous images read with ds_read_b32).
+// Tile: 128(M) x 64(N) x 32(K), 512 threads = 8 waves, each wave one 32x32 accumulator (4 along M x 2 along N): the
+// dominant launches have only 2 blocks per CU, so the waves that hide the loader/barrier latency must come from the block.
+// LDS images carry no padding (48 KB double-buffered -> three blocks per CU): k-contiguous images ([row][32 k], read
+// with ds_read_b128) XOR-swizzle the 16-byte k-group with (row & 7) so that 8 consecutive rows cover all 32 banks;
+// row-contiguous images ([k][row], read with ds_read_b32 over 32 consecutive rows) are conflict free as they are.
 // The k order inside an 8-wide k-group is permuted identically for A and B (lane half h takes k = 4h+e),
 // which lets k-contiguous operands be read as one b128 per 4 MFMAs.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 64, BK = 32;
-constexpr int LDK = BK + 4;    // k-contiguous LDS image row stride (floats)
-constexpr int LDA_M = BM + 4;  // row-contiguous A image: [k][m]
-constexpr int LDB_N = BN + 4;  // row-contiguous B image: [k][n]
-constexpr int A_FLOATS = (BM * LDK > BK * LDA_M) ? BM * LDK : BK * LDA_M;
-constexpr int B_FLOATS = (BN * LDK > BK * LDB_N) ? BN * LDK : BK * LDB_N;
+constexpr int BM = 128, BN = 64, BK = 32, NTHR = 512;
+constexpr int LDK = BK;    // k-contiguous LDS image row stride (floats), k-groups swizzled
+constexpr int LDA_M = BM;  // row-contiguous A image: [k][m]
+constexpr int LDB_N = BN;  // row-contiguous B image: [k][n]
+constexpr int A_FLOATS = BM * BK;
+constexpr int B_FLOATS = BN * BK;
 
 enum { OP_STRIDED = 0, OP_ROWCONTIG = 1, OP_IM2COL = 2, OP_CONVW = 3, OP_IM2COL_N = 4, OP_IM2COL_M = 5 };
 
@@ -56,13 +58,50 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, bool vec_ok, long st
   return v;
 }
 
+// predicated 16-byte load without a branch: lanes that are off read a valid dummy address and discard it
+__device__ __forceinline__ float4 ld4_if(const float* p, bool ok, const float* safe) {
+  const float4 v = *reinterpret_cast<const float4*>(ok ? p : safe);
+  return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// k = k0 + off with k0 wave-uniform (a multiple of BK) and 0 <= off < BK: split into (tap, ci) for k = tap*Cin + ci.
+// The division runs once per wave on the scalar unit; lanes only add their offset (Cin % BK == 0 makes that exact).
+__device__ __forceinline__ void split_tap(int k0, int off, int Cin, int& tap, int& ci) {
+  const int k0u = __builtin_amdgcn_readfirstlane(k0);
+  tap = k0u / Cin;
+  ci = k0u - tap * Cin + off;
+  while (ci >= Cin) {
+    ci -= Cin;
+    ++tap;
+  }
+}
+
+// pixel index k = k0 + off -> (b, y, x) of an H x W image batch; same uniform-division trick
+__device__ __forceinline__ void split_pixel(int k0, int off, int H, int W, int& b, int& y, int& x) {
+  const int k0u = __builtin_amdgcn_readfirstlane(k0);
+  const int hw = H * W;
+  b = k0u / hw;
+  const int rem = k0u - b * hw;
+  y = rem / W;
+  x = rem - y * W + off;
+  while (x >= W) {
+    x -= W;
+    ++y;
+  }
+  while (y >= H) {
+    y -= H;
+    ++b;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int AOP, int BOP>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 3, wn = wave >> 2;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int zb = blockIdx.z / a.splitk, zs = blockIdx.z % a.splitk;
   const float* __restrict__ Ap = a.A + zb * a.sAb;
@@ -72,16 +111,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
   const int ntiles = (kend - kbeg + BK - 1) / BK;
 
   // ---- per-thread loader state -------------------------------------------------------------
-  // k-contiguous images: thread -> (rows r0+32j, k offset kq*4)
+  // k-contiguous images: thread -> (A rows r0 and r0+64, B row r0, k offset kq*4)
   const int kq = tid & 7, r0 = tid >> 3;
-  // A row-contiguous: m offset (tid&31)*4, k rows (tid>>5)+8j ; B row-contiguous: n offset (tid&15)*4, k rows (tid>>4)+16j
-  int a_py[4], a_px[4];
-  long a_base[4];
-  bool a_rowok[4];
+  // A row-contiguous: m offset (tid&31)*4, k rows (tid>>5)+16j ; B row-contiguous: n offset (tid&15)*4, k row tid>>4
+  int a_py[2], a_px[2];
+  long a_base[2];
+  bool a_rowok[2];
   if constexpr (AOP == OP_IM2COL) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int m = m0 + r0 + 32 * j;
+    for (int j = 0; j < 2; ++j) {
+      int m = m0 + r0 + 64 * j;
       a_rowok[j] = m < a.M;
       int hw = a.g.H * a.g.W;
       int b = m / hw, rem = m - b * hw;
@@ -95,6 +134,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
   const bool b_vec = (BOP == OP_STRIDED) && a.sbk == 1 && (a.sbn % 4 == 0) && ((((uintptr_t)Bp) & 15) == 0);
   const bool a_rvec = (AOP == OP_ROWCONTIG) && (a.sak % 4 == 0) && ((((uintptr_t)Ap) & 15) == 0);
   const bool b_rvec = (BOP == OP_ROWCONTIG) && (a.sbk % 4 == 0) && ((((uintptr_t)Bp) & 15) == 0);
+  // packed conv weights ([n][tap][ci], see tatt_conv_pack_w): 4 consecutive ci are one 16-byte load
+  const bool w_vec = (BOP == OP_CONVW) && a.w_sci == 1 && ((a.w_sn | a.w_stap | a.w_base) % 4 == 0) && ((((uintptr_t)Bp) & 15) == 0);
   // OP_IM2COL_N (wgrad B operand): n = (tap, ci) fixed per thread
   int bn_tap_dy = 0, bn_tap_dx = 0, bn_ci = 0;
   bool bn_ok = false;
@@ -119,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
     am_tap_dx = tap % a.g.KW - a.g.padW;
   }
 
-  float4 ra[4], rb[2];
+  float4 ra[2], rb;
 
   auto load_tiles = [&](int k0) {
     // ---- A ----
@@ -127,120 +168,112 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
       int k = k0 + kq * 4;
       int nv = min(4, kend - k);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int m = m0 + r0 + 32 * j;
+      for (int j = 0; j < 2; ++j) {
+        int m = m0 + r0 + 64 * j;
         ra[j] = ld4_guard(Ap + (long)m * a.sam + (long)k * a.sak, a_vec, a.sak, m < a.M ? nv : 0);
       }
     } else if constexpr (AOP == OP_ROWCONTIG) {
       int m = m0 + (tid & 31) * 4;
       int nv = min(4, a.M - m);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int k = k0 + (tid >> 5) + 8 * j;
+      for (int j = 0; j < 2; ++j) {
+        int k = k0 + (tid >> 5) + 16 * j;
         ra[j] = ld4_guard(Ap + (long)k * a.sak + m, a_rvec, 1, k < kend ? nv : 0);
       }
     } else if constexpr (AOP == OP_IM2COL_M) {
       int hw = a.g.H * a.g.W;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int k = k0 + (tid >> 5) + 8 * j;
+      for (int j = 0; j < 2; ++j) {
+        int k = k0 + (tid >> 5) + 16 * j;
         bool ok = am_ok && k < kend;
-        int b = k / hw, rem = k - b * hw;
-        int y = rem / a.g.W, x = rem - y * a.g.W;
+        int b, y, x;
+        split_pixel(k0, (tid >> 5) + 16 * j, a.g.H, a.g.W, b, y, x);
         y += am_tap_dy;
         x += am_tap_dx;
-        ok = ok && y >= 0 && y < a.g.H && x >= 0 && x < a.g.W;
-        ra[j] = ok ? *reinterpret_cast<const float4*>(Ap + ((long)b * hw + (long)y * a.g.W + x) * a.g.ldx + am_ci)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        ok = ok && (unsigned)y < (unsigned)a.g.H && (unsigned)x < (unsigned)a.g.W;
+        ra[j] = ld4_if(Ap + ((long)b * hw + (long)y * a.g.W + x) * a.g.ldx + am_ci, ok, Ap);
       }
     } else {  // OP_IM2COL: k = tap*Cin + ci, 4 consecutive k share a tap (Cin % 4 == 0)
       int k = k0 + kq * 4;
       bool kok = k < kend;
-      int tap = k / a.g.Cin, ci = k - tap * a.g.Cin;
+      int tap, ci;
+      split_tap(k0, kq * 4, a.g.Cin, tap, ci);
       int dy = tap / a.g.KW - a.g.padH, dx = tap % a.g.KW - a.g.padW;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 2; ++j) {
         int y = a_py[j] + dy, x = a_px[j] + dx;
-        bool ok = kok && a_rowok[j] && y >= 0 && y < a.g.H && x >= 0 && x < a.g.W;
-        ra[j] = ok ? *reinterpret_cast<const float4*>(Ap + (a_base[j] + (long)y * a.g.W + x) * a.g.ldx + ci)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        bool ok = kok && a_rowok[j] && (unsigned)y < (unsigned)a.g.H && (unsigned)x < (unsigned)a.g.W;
+        ra[j] = ld4_if(Ap + (a_base[j] + (long)y * a.g.W + x) * a.g.ldx + ci, ok, Ap);
       }
     }
     // ---- B ----
     if constexpr (BOP == OP_STRIDED) {
       int k = k0 + kq * 4;
       int nv = min(4, kend - k);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int n = n0 + r0 + 32 * j;
-        rb[j] = ld4_guard(Bp + (long)n * a.sbn + (long)k * a.sbk, b_vec, a.sbk, n < a.N ? nv : 0);
+      {
+        int n = n0 + r0;
+        rb = ld4_guard(Bp + (long)n * a.sbn + (long)k * a.sbk, b_vec, a.sbk, n < a.N ? nv : 0);
       }
     } else if constexpr (BOP == OP_ROWCONTIG) {
       int n = n0 + (tid & 15) * 4;
       int nv = min(4, a.N - n);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int k = k0 + (tid >> 4) + 16 * j;
-        rb[j] = ld4_guard(Bp + (long)k * a.sbk + n, b_rvec, 1, k < kend ? nv : 0);
+      {
+        int k = k0 + (tid >> 4);
+        rb = ld4_guard(Bp + (long)k * a.sbk + n, b_rvec, 1, k < kend ? nv : 0);
       }
     } else if constexpr (BOP == OP_CONVW) {
       int k = k0 + kq * 4;
       bool kok = k < kend;
-      int tap = k / a.g.Cin, ci = k - tap * a.g.Cin;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int n = n0 + r0 + 32 * j;
-        if (kok && n < a.N) {
-          const float* p = Bp + (long)n * a.w_sn + (long)ci * a.w_sci + a.w_base + (long)tap * a.w_stap;
-          rb[j] = make_float4(p[0], p[a.w_sci], p[2 * a.w_sci], p[3 * a.w_sci]);
+      int tap, ci;
+      split_tap(k0, kq * 4, a.g.Cin, tap, ci);
+      {
+        int n = n0 + r0;
+        const float* p = Bp + (long)n * a.w_sn + (long)ci * a.w_sci + a.w_base + (long)tap * a.w_stap;
+        if (w_vec) {
+          rb = ld4_if(p, kok && n < a.N, Bp);
+        } else if (kok && n < a.N) {
+          rb = make_float4(p[0], p[a.w_sci], p[2 * a.w_sci], p[3 * a.w_sci]);
         } else {
-          rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          rb = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
     } else {  // OP_IM2COL_N : B(n=(tap,ci), k=pixel) = X[pixel shifted by tap][ci], row(n)-contiguous image
       int hw = a.g.H * a.g.W;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int k = k0 + (tid >> 4) + 16 * j;
+      {
+        int k = k0 + (tid >> 4);
         bool ok = bn_ok && k < kend;
-        int b = k / hw, rem = k - b * hw;
-        int y = rem / a.g.W, x = rem - y * a.g.W;
+        int b, y, x;
+        split_pixel(k0, tid >> 4, a.g.H, a.g.W, b, y, x);
         y += bn_tap_dy;
         x += bn_tap_dx;
-        ok = ok && y >= 0 && y < a.g.H && x >= 0 && x < a.g.W;
-        rb[j] = ok ? *reinterpret_cast<const float4*>(Bp + ((long)b * hw + (long)y * a.g.W + x) * a.g.ldx + bn_ci)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        ok = ok && (unsigned)y < (unsigned)a.g.H && (unsigned)x < (unsigned)a.g.W;
+        rb = ld4_if(Bp + ((long)b * hw + (long)y * a.g.W + x) * a.g.ldx + bn_ci, ok, Bp);
       }
     }
   };
 
+  const int st_swz = (kq ^ (r0 & 7)) * 4;  // rows r0 and r0 + 64 share r0 & 7
   auto store_tiles = [&](int buf) {
     float* As = lds + buf * (A_FLOATS + B_FLOATS);
     float* Bs = As + A_FLOATS;
     if constexpr (AOP == OP_ROWCONTIG || AOP == OP_IM2COL_M) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<float4*>(As + ((tid >> 5) + 8 * j) * LDA_M + (tid & 31) * 4) = ra[j];
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<float4*>(As + ((tid >> 5) + 16 * j) * LDA_M + (tid & 31) * 4) = ra[j];
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(As + (r0 + 32 * j) * LDK + kq * 4) = ra[j];
+      for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(As + (r0 + 64 * j) * LDK + st_swz) = ra[j];
     }
     if constexpr (BOP == OP_ROWCONTIG || BOP == OP_IM2COL_N) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        *reinterpret_cast<float4*>(Bs + ((tid >> 4) + 16 * j) * LDB_N + (tid & 15) * 4) = rb[j];
+      *reinterpret_cast<float4*>(Bs + (tid >> 4) * LDB_N + (tid & 15) * 4) = rb;
     } else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * LDK + kq * 4) = rb[j];
+      *reinterpret_cast<float4*>(Bs + r0 * LDK + st_swz) = rb;
     }
   };
 
-  f32x16 acc0, acc1;
+  f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    acc0[i] = 0.f;
-    acc1[i] = 0.f;
-  }
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
   if (ntiles > 0) {
     load_tiles(kbeg);
@@ -254,31 +287,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
     const float* Bs = As + A_FLOATS;
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
-      float av[4], b0[4], b1[4];
+      float av[4], bv[4];
       if constexpr (AOP == OP_ROWCONTIG || AOP == OP_IM2COL_M) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) av[e] = As[(kg * 8 + 4 * lh + e) * LDA_M + wave * 32 + li];
+        for (int e = 0; e < 4; ++e) av[e] = As[(kg * 8 + 4 * lh + e) * LDA_M + wm * 32 + li];
       } else {
-        float4 v = *reinterpret_cast<const float4*>(As + (wave * 32 + li) * LDK + kg * 8 + 4 * lh);
+        float4 v = *reinterpret_cast<const float4*>(As + (wm * 32 + li) * LDK + (((2 * kg + lh) ^ (li & 7)) << 2));
         av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
       }
       if constexpr (BOP == OP_ROWCONTIG || BOP == OP_IM2COL_N) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          b0[e] = Bs[(kg * 8 + 4 * lh + e) * LDB_N + li];
-          b1[e] = Bs[(kg * 8 + 4 * lh + e) * LDB_N + 32 + li];
-        }
+        for (int e = 0; e < 4; ++e) bv[e] = Bs[(kg * 8 + 4 * lh + e) * LDB_N + wn * 32 + li];
       } else {
-        float4 v = *reinterpret_cast<const float4*>(Bs + li * LDK + kg * 8 + 4 * lh);
-        float4 w = *reinterpret_cast<const float4*>(Bs + (32 + li) * LDK + kg * 8 + 4 * lh);
-        b0[0] = v.x; b0[1] = v.y; b0[2] = v.z; b0[3] = v.w;
-        b1[0] = w.x; b1[1] = w.y; b1[2] = w.z; b1[3] = w.w;
+        float4 v = *reinterpret_cast<const float4*>(Bs + (wn * 32 + li) * LDK + (((2 * kg + lh) ^ (li & 7)) << 2));
+        bv[0] = v.x; bv[1] = v.y; bv[2] = v.z; bv[3] = v.w;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], b0[e], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], b1[e], acc1, 0, 0, 0);
-      }
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
     }
     if (t + 1 < ntiles) store_tiles(cur ^ 1);
     __syncthreads();
@@ -287,16 +312,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
   // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ------------------
   float* Cp = a.C + zb * a.sCb + zs * a.sCz;
   const bool plain = a.splitk == 1;
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    int n = n0 + nt * 32 + li;
-    if (n >= a.N) continue;
+  {
+    int n = n0 + wn * 32 + li;
+    if (n >= a.N) return;
     float bv = (plain && a.bias) ? a.bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m >= a.M) continue;
-      float v = (nt == 0 ? acc0[r] : acc1[r]) + bv;
+      float v = acc[r] + bv;
       float* dst = Cp + (long)m * a.ldc + n;
       if (plain) {
         if (a.accumulate) v += *dst;
@@ -350,6 +374,20 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_
 // ---- skinny-Cout convolution (Cout <= 16: the 9x9 64->4 output conv and the 9x9 dgrad of block1) ----------------
 // A Cout of 4 would fill 1/16 of the 64-wide MFMA N tile.  Instead: Z[(tap,co)][pixel] = sum_ci Wr[(tap,co)][ci] * X[pixel][ci]
 // (a dense GEMM with M = T*Cout, K = Cin, planar output), then Y[p][co] = bias + sum_tap Z[(tap,co)][p + shift(tap)].
+// Wf[co][tap][ci] = W[co][ci][tap] ; Wd[ci][tap][co] = W[co][ci][T-1-tap]  (W is OIHW)
+__global__ void conv_pack_w_kernel(const float* __restrict__ Wt, float* __restrict__ Wf, float* __restrict__ Wd, int Cout, int Cin, int T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cout * Cin * T) return;
+  {
+    const int ci = i % Cin, tap = (i / Cin) % T, co = i / (Cin * T);
+    Wf[i] = Wt[((long)co * Cin + ci) * T + tap];
+  }
+  {
+    const int co = i % Cout, tap = (i / Cout) % T, ci = i / (Cout * T);
+    Wd[i] = Wt[((long)co * Cin + ci) * T + (T - 1 - tap)];
+  }
+}
+
 __global__ void skinny_repack_w(const float* __restrict__ Wt, float* __restrict__ Wr, int Cin, int Cout, int T, long w_sn, long w_sci,
                                 long w_base, long w_stap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;  // (tap, co, ci)
@@ -391,7 +429,7 @@ __global__ __launch_bounds__(256) void skinny_gather(const float* __restrict__ Z
 template <int AOP, int BOP>
 int launch(const GemmArgs& a, int batch, hipStream_t st) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch * a.splitk);
-  hipLaunchKernelGGL((gemm_kernel<AOP, BOP>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((gemm_kernel<AOP, BOP>), grid, dim3(NTHR), 0, st, a);
   TATT_LAUNCH_CHECK("gemm_kernel");
   return TATT_OK;
 }
@@ -399,6 +437,14 @@ int launch(const GemmArgs& a, int batch, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+int tatt_conv_pack_w(const float* Wt, float* Wf, float* Wd, int Cout, int Cin, int KH, int KW, hipStream_t st) {
+  TATT_CHECK_ARG(Wt && Wf && Wd && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "tatt_conv_pack_w: bad arguments");
+  const int n = Cout * Cin * KH * KW;
+  hipLaunchKernelGGL(conv_pack_w_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, Wt, Wf, Wd, Cout, Cin, KH * KW);
+  TATT_LAUNCH_CHECK("conv_pack_w_kernel");
+  return TATT_OK;
+}
 
 // Workspace floats needed by a split-K call (0 when splitk <= 1).
 size_t tatt_gemm_workspace(int M, int N, int splitk) { return splitk > 1 ? (size_t)M * N * splitk : 0; }
@@ -534,7 +580,7 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
     perm = 3;
     perm_c = Cout;
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), splitk);
-    hipLaunchKernelGGL((gemm_kernel<OP_ROWCONTIG, OP_IM2COL_N>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemm_kernel<OP_ROWCONTIG, OP_IM2COL_N>), grid, dim3(NTHR), 0, st, a);
   } else if (Cout <= 64 && lddy % 4 == 0 && (((uintptr_t)dY) & 15) == 0) {
     // Cout <= 64 fits ONE 64-wide N tile: put (tap,ci) on the 128-wide M side so that no MFMA rows are padding
     // (with Cout on M a 64-channel conv would fill only half of every 128-row tile).
@@ -546,11 +592,11 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
     a.sCz = (long)a.M * a.N;
     perm = 2;
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), splitk);
-    hipLaunchKernelGGL((gemm_kernel<OP_IM2COL_M, OP_ROWCONTIG>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemm_kernel<OP_IM2COL_M, OP_ROWCONTIG>), grid, dim3(NTHR), 0, st, a);
   } else {
     // the kernel treats splitk>1 as "write raw slabs"; with splitk==1 it applies bias/accumulate (none set): same result.
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), splitk);
-    hipLaunchKernelGGL((gemm_kernel<OP_ROWCONTIG, OP_IM2COL_N>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemm_kernel<OP_ROWCONTIG, OP_IM2COL_N>), grid, dim3(NTHR), 0, st, a);
   }
   TATT_LAUNCH_CHECK("conv_wgrad");
   long tot = (long)a.M * a.N;

@@ -47,6 +47,7 @@ class Engine:
         self.P = {}
         self.debug = None         # set to a dict to stash intermediate gradients (tools/debug_grads.py)
         self.seed_dev = None      # optional uint32 device tensor added to the dropout seed (graph-captured training)
+        self.wpack = {}
 
     # ---- parameters --------------------------------------------------------------------------------
     def param_list(self):
@@ -119,18 +120,30 @@ class Engine:
         z = self.new(wsz)                                      # planar Z [(tap,co)][pixel]: 340 MB for the output conv at B=64
         self.L.conv_skinny_fwd(x, W, b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout, *wstr, acc, z)
 
+    def _packed(self, W, Cout, Cin, k):
+        """(Wf [co][tap][ci], Wd [ci][flipped tap][co]) of an OIHW weight, packed once per forward call (tatt_conv_pack_w)."""
+        key = W.data_ptr()
+        pk = self.wpack.get(key)
+        if pk is None:
+            pk = (self.new(W.numel()), self.new(W.numel()))
+            self.L.conv_pack_w(W, pk[0], pk[1], Cout, Cin, k, k)
+            self.wpack[key] = pk
+        return pk
+
     def conv(self, x, W, b, out, B, H, Wd, Cin, Cout, k, acc=0, relu=0):
         T = k * k
         if Cout in (4, 8, 16) and not relu:
             return self._skinny(x, W, b, out, B, H, Wd, Cin, Cout, k, (Cin * T, T, 0, 1), acc)
-        self.L.conv_fwd(x, W, b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout, Cin * T, T, 0, 1, acc, relu)
+        self.L.conv_fwd(x, self._packed(W, Cout, Cin, k)[0], b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout,
+                        T * Cin, 1, 0, Cin, acc, relu)
 
     def conv_dgrad(self, dy, W, dx, B, H, Wd, Cin, Cout, k, acc=0):
         """dx[B,H,W,Cin] (+)= conv^T(dy[B,H,W,Cout]);  W is the forward OIHW weight [Cout,Cin,k,k]."""
         T = k * k
         if Cin in (4, 8, 16):
             return self._skinny(dy, W, None, dx, B, H, Wd, Cout, Cin, k, (T, Cin * T, T - 1, -1), acc)
-        self.L.conv_fwd(dy, W, None, dx, B, H, Wd, Cout, Cin, k, k, Cout, Cin, T, Cin * T, T - 1, -1, acc, 0)
+        self.L.conv_fwd(dy, self._packed(W, Cout, Cin, k)[1], None, dx, B, H, Wd, Cout, Cin, k, k, Cout, Cin,
+                        T * Cout, 1, 0, Cout, acc, 0)
 
     def conv_wgrad(self, x, dy, dW, db, B, H, Wd, Cin, Cout, k):
         T = k * k
@@ -301,6 +314,7 @@ class Engine:
         cfg = lambda site: self.dropcfg(site, seed, p)
         ctx = Ctx()
         ctx["meta"] = (B, training, seed, p)
+        self.wpack = ctx["wpack"] = {}                       # weights change every step: repacked per forward call
         R0 = B * H * W
         use_stn = bool(m.stn and training)
         ctx["x"] = x
@@ -457,6 +471,7 @@ class Engine:
         on_stage = on_stage or (lambda name: None)
         L, m, P = self.L, self.m, self.P
         B, training, seed, p = ctx["meta"]
+        self.wpack = ctx["wpack"]
         cfg = lambda site: self.dropcfg(site, seed, p)
         H, W = 16, 64
         R0 = B * H * W

@@ -96,6 +96,13 @@ def test_conv_fwd_dgrad_wgrad(B, H, W, Cin, Cout, k):
     dx = torch.empty(B, H, W, Cin, device="cuda")
     L().conv_fwd(dyn, cu(w.detach()), None, dx, B, H, W, Cout, Cin, k, k, Cout, Cin, T, Cin * T, T - 1, -1, 0, 0)
     close(dx.permute(0, 3, 1, 2), x.grad, what="dgrad")
+    # the per-step packed layouts the engine uses: bitwise the same sums in the same order
+    wf, wd = torch.empty(w.numel(), device="cuda"), torch.empty(w.numel(), device="cuda")
+    L().conv_pack_w(cu(w.detach()), wf, wd, Cout, Cin, k, k)
+    out2, dx2 = torch.empty_like(out), torch.empty_like(dx)
+    L().conv_fwd(xn, wf, cu(b.detach()), out2, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, 0, 0)
+    L().conv_fwd(dyn, wd, None, dx2, B, H, W, Cout, Cin, k, k, Cout, Cin, T * Cout, 1, 0, Cout, 0, 0)
+    assert torch.equal(out2, out) and torch.equal(dx2, dx)
     for sk in (1, 4):
         dW = torch.zeros(Cout, Cin, k, k, device="cuda")
         L().conv_wgrad(xn, dyn, dW, B, H, W, Cin, Cout, k, k, Cin, Cout, sk, ws(), 1)

@@ -28,6 +28,10 @@ def rnd(*s):
 
 x64, y64, w33, b64 = rnd(R, 64), rnd(R, 64), rnd(64, 64, 3, 3), rnd(64)
 t("conv3x3 64->64 fwd", lambda: L.conv_fwd(x64, w33, b64, y64, B, 16, 64, 64, 64, 3, 3, 64, 64, 576, 9, 0, 1, 0, 0), 2 * R * 64 * 576, R * 512)
+wf33, wd33 = rnd(64 * 576), rnd(64 * 576)
+L.conv_pack_w(w33, wf33, wd33, 64, 64, 3, 3)
+t("conv3x3 64->64 fwd packed", lambda: L.conv_fwd(x64, wf33, b64, y64, B, 16, 64, 64, 64, 3, 3, 64, 64, 576, 1, 0, 64, 0, 0), 2 * R * 64 * 576, R * 512)
+t("conv_pack_w 64x64x3x3", lambda: L.conv_pack_w(w33, wf33, wd33, 64, 64, 3, 3), 0, 64 * 576 * 12)
 t("conv3x3 64->64 dgrad", lambda: L.conv_fwd(x64, w33, None, y64, B, 16, 64, 64, 64, 3, 3, 64, 64, 9, 576, 8, -1, 0, 0), 2 * R * 64 * 576, R * 512)
 dw = rnd(64, 64, 3, 3)
 for sk in (8, 16, 32, 64):
