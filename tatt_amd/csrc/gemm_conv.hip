@@ -20,7 +20,7 @@ constexpr int LDB_N = BN;  // row-contiguous B image: [k][n]
 constexpr int A_FLOATS = BM * BK;
 constexpr int B_FLOATS = BN * BK;
 
-enum { OP_STRIDED = 0, OP_ROWCONTIG = 1, OP_IM2COL = 2, OP_CONVW = 3, OP_IM2COL_N = 4, OP_IM2COL_M = 5 };
+enum { OP_STRIDED = 0, OP_ROWCONTIG = 1, OP_IM2COL = 2, OP_CONVW = 3, OP_IM2COL_N = 4, OP_IM2COL_M = 5, OP_CONVW_P = 6 };
 
 struct ConvGeom {
   int H, W, Cin, KH, KW, padH, padW;
@@ -58,21 +58,36 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, bool vec_ok, long st
   return v;
 }
 
-// predicated 16-byte load without a branch: lanes that are off read a valid dummy address and discard it
-__device__ __forceinline__ float4 ld4_if(const float* p, bool ok, const float* safe) {
-  const float4 v = *reinterpret_cast<const float4*>(ok ? p : safe);
-  return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+// Predicated 16-byte loads without branches: a raw buffer descriptor spanning 2 GiB from the operand base; lanes that are
+// off use a byte offset beyond num_records, for which buffer_load returns zeros.  The entry points check that every
+// valid offset of the im2col operands stays below 2 GiB.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int BUF_OOB = (int)0x80000000;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, BUF_OOB, 0x00020000);
+}
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, int byte_off, bool ok) {
+  i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? byte_off : BUF_OOB, 0, 0);
+  return *reinterpret_cast<float4*>(&v);
 }
 
-// k = k0 + off with k0 wave-uniform (a multiple of BK) and 0 <= off < BK: split into (tap, ci) for k = tap*Cin + ci.
-// The division runs once per wave on the scalar unit; lanes only add their offset (Cin % BK == 0 makes that exact).
-__device__ __forceinline__ void split_tap(int k0, int off, int Cin, int& tap, int& ci) {
+// (tap, ci, dy, dx) of k = k0 + off, k = tap*Cin + ci.  When a K tile never straddles a tap (Cin % BK == 0) everything but
+// ci is wave-uniform and is computed on the scalar unit.
+__device__ __forceinline__ void tap_geom(int k0, int off, int Cin, int KW, int padH, int padW, int& tap, int& ci, int& dy, int& dx) {
   const int k0u = __builtin_amdgcn_readfirstlane(k0);
-  tap = k0u / Cin;
-  ci = k0u - tap * Cin + off;
-  while (ci >= Cin) {
-    ci -= Cin;
-    ++tap;
+  if (Cin % BK == 0) {
+    const int t = k0u / Cin;
+    tap = t;
+    ci = k0u - t * Cin + off;
+    const int ty = t / KW;
+    dy = ty - padH;
+    dx = t - ty * KW - padW;
+  } else {
+    const int k = k0u + off, t = k / Cin, c = k - t * Cin;  // per-lane division: only the Cin < 32 convolutions come here
+    tap = t;
+    ci = c;
+    dy = t / KW - padH;
+    dx = t % KW - padW;
   }
 }
 
@@ -114,30 +129,33 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   // k-contiguous images: thread -> (A rows r0 and r0+64, B row r0, k offset kq*4)
   const int kq = tid & 7, r0 = tid >> 3;
   // A row-contiguous: m offset (tid&31)*4, k rows (tid>>5)+16j ; B row-contiguous: n offset (tid&15)*4, k row tid>>4
-  int a_py[2], a_px[2];
-  long a_base[2];
-  bool a_rowok[2];
+  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(Ap), rsrcB = make_rsrc(Bp);
+  int a_py[2], a_px[2], a_off[2];  // OP_IM2COL: pixel (y, x) of the thread's rows and their byte offset (tap (0,0), ci 0)
   if constexpr (AOP == OP_IM2COL) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int m = m0 + r0 + 64 * j;
-      a_rowok[j] = m < a.M;
       int hw = a.g.H * a.g.W;
       int b = m / hw, rem = m - b * hw;
       int y = rem / a.g.W, x = rem - y * a.g.W;
-      a_py[j] = y;
+      a_py[j] = m < a.M ? y : -(1 << 20);  // rows past M fail every bounds test
       a_px[j] = x;
-      a_base[j] = (long)b * hw;
+      a_off[j] = m < a.M ? m * a.g.ldx * 4 : 0;
     }
+  }
+  int bw_off = 0;  // packed OP_CONVW: byte offset of (n, tap 0, ci 0)
+  bool bw_ok = false;
+  if constexpr (BOP == OP_CONVW_P) {
+    bw_ok = n0 + r0 < a.N;
+    bw_off = bw_ok ? (int)(((long)(n0 + r0) * a.w_sn + a.w_base) * 4) : 0;
   }
   const bool a_vec = (AOP == OP_STRIDED) && a.sak == 1 && (a.sam % 4 == 0) && ((((uintptr_t)Ap) & 15) == 0);
   const bool b_vec = (BOP == OP_STRIDED) && a.sbk == 1 && (a.sbn % 4 == 0) && ((((uintptr_t)Bp) & 15) == 0);
   const bool a_rvec = (AOP == OP_ROWCONTIG) && (a.sak % 4 == 0) && ((((uintptr_t)Ap) & 15) == 0);
   const bool b_rvec = (BOP == OP_ROWCONTIG) && (a.sbk % 4 == 0) && ((((uintptr_t)Bp) & 15) == 0);
   // packed conv weights ([n][tap][ci], see tatt_conv_pack_w): 4 consecutive ci are one 16-byte load
-  const bool w_vec = (BOP == OP_CONVW) && a.w_sci == 1 && ((a.w_sn | a.w_stap | a.w_base) % 4 == 0) && ((((uintptr_t)Bp) & 15) == 0);
   // OP_IM2COL_N (wgrad B operand): n = (tap, ci) fixed per thread
-  int bn_tap_dy = 0, bn_tap_dx = 0, bn_ci = 0;
+  int bn_tap_dy = 0, bn_tap_dx = 0, bn_ci = 0, bn_off = 0;
   bool bn_ok = false;
   if constexpr (BOP == OP_IM2COL_N) {
     int n = n0 + (tid & 15) * 4;
@@ -146,10 +164,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
     bn_ci = n - tap * a.g.Cin;
     bn_tap_dy = tap / a.g.KW - a.g.padH;
     bn_tap_dx = tap % a.g.KW - a.g.padW;
+    bn_off = ((bn_tap_dy * a.g.W + bn_tap_dx) * a.g.ldx + bn_ci) * 4;
   }
 
   // OP_IM2COL_M (wgrad A operand when Cout is tiny): m = (tap, ci) fixed per thread, row(m)-contiguous image
-  int am_tap_dy = 0, am_tap_dx = 0, am_ci = 0;
+  int am_tap_dy = 0, am_tap_dx = 0, am_ci = 0, am_off = 0;
   bool am_ok = false;
   if constexpr (AOP == OP_IM2COL_M) {
     int m = m0 + (tid & 31) * 4;
@@ -158,11 +177,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
     am_ci = m - tap * a.g.Cin;
     am_tap_dy = tap / a.g.KW - a.g.padH;
     am_tap_dx = tap % a.g.KW - a.g.padW;
+    am_off = ((am_tap_dy * a.g.W + am_tap_dx) * a.g.ldx + am_ci) * 4;
   }
 
-  float4 ra[2], rb;
+  // two register sets: the tiles t+1 and t+2 are in flight while tile t is multiplied (global latency under load is
+  // longer than one 16-MFMA tile, a prefetch distance of one tile left the MFMA pipe idle half of the time)
+  float4 ra0[2], rb0, ra1[2], rb1;
 
-  auto load_tiles = [&](int k0) {
+  auto load_tiles = [&](int k0, float4 (&ra)[2], float4& rb) {
     // ---- A ----
     if constexpr (AOP == OP_STRIDED) {
       int k = k0 + kq * 4;
@@ -188,22 +210,19 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
         bool ok = am_ok && k < kend;
         int b, y, x;
         split_pixel(k0, (tid >> 5) + 16 * j, a.g.H, a.g.W, b, y, x);
-        y += am_tap_dy;
-        x += am_tap_dx;
-        ok = ok && (unsigned)y < (unsigned)a.g.H && (unsigned)x < (unsigned)a.g.W;
-        ra[j] = ld4_if(Ap + ((long)b * hw + (long)y * a.g.W + x) * a.g.ldx + am_ci, ok, Ap);
+        ok = ok && (unsigned)(y + am_tap_dy) < (unsigned)a.g.H && (unsigned)(x + am_tap_dx) < (unsigned)a.g.W;
+        ra[j] = bload4(rsrcA, ((b * hw + y * a.g.W + x) * a.g.ldx) * 4 + am_off, ok);
       }
     } else {  // OP_IM2COL: k = tap*Cin + ci, 4 consecutive k share a tap (Cin % 4 == 0)
       int k = k0 + kq * 4;
       bool kok = k < kend;
-      int tap, ci;
-      split_tap(k0, kq * 4, a.g.Cin, tap, ci);
-      int dy = tap / a.g.KW - a.g.padH, dx = tap % a.g.KW - a.g.padW;
+      int tap, ci, dy, dx;
+      tap_geom(k0, kq * 4, a.g.Cin, a.g.KW, a.g.padH, a.g.padW, tap, ci, dy, dx);
+      const int delta = ((dy * a.g.W + dx) * a.g.ldx + ci) * 4;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        int y = a_py[j] + dy, x = a_px[j] + dx;
-        bool ok = kok && a_rowok[j] && (unsigned)y < (unsigned)a.g.H && (unsigned)x < (unsigned)a.g.W;
-        ra[j] = ld4_if(Ap + (a_base[j] + (long)y * a.g.W + x) * a.g.ldx + ci, ok, Ap);
+        bool ok = kok && (unsigned)(a_py[j] + dy) < (unsigned)a.g.H && (unsigned)(a_px[j] + dx) < (unsigned)a.g.W;
+        ra[j] = bload4(rsrcA, a_off[j] + delta, ok);
       }
     }
     // ---- B ----
@@ -221,17 +240,17 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
         int k = k0 + (tid >> 4);
         rb = ld4_guard(Bp + (long)k * a.sbk + n, b_rvec, 1, k < kend ? nv : 0);
       }
-    } else if constexpr (BOP == OP_CONVW) {
+    } else if constexpr (BOP == OP_CONVW || BOP == OP_CONVW_P) {
       int k = k0 + kq * 4;
       bool kok = k < kend;
-      int tap, ci;
-      split_tap(k0, kq * 4, a.g.Cin, tap, ci);
-      {
+      int tap, ci, dy, dx;
+      tap_geom(k0, kq * 4, a.g.Cin, a.g.KW, a.g.padH, a.g.padW, tap, ci, dy, dx);
+      if constexpr (BOP == OP_CONVW_P) {  // packed [n][tap][ci] (tatt_conv_pack_w): one 16-byte load, no branch
+        rb = bload4(rsrcB, bw_off + (tap * (int)a.w_stap + ci) * 4, kok && bw_ok);
+      } else {
         int n = n0 + r0;
         const float* p = Bp + (long)n * a.w_sn + (long)ci * a.w_sci + a.w_base + (long)tap * a.w_stap;
-        if (w_vec) {
-          rb = ld4_if(p, kok && n < a.N, Bp);
-        } else if (kok && n < a.N) {
+        if (kok && n < a.N) {
           rb = make_float4(p[0], p[a.w_sci], p[2 * a.w_sci], p[3 * a.w_sci]);
         } else {
           rb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -244,16 +263,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
         bool ok = bn_ok && k < kend;
         int b, y, x;
         split_pixel(k0, tid >> 4, a.g.H, a.g.W, b, y, x);
-        y += bn_tap_dy;
-        x += bn_tap_dx;
-        ok = ok && (unsigned)y < (unsigned)a.g.H && (unsigned)x < (unsigned)a.g.W;
-        rb = ld4_if(Bp + ((long)b * hw + (long)y * a.g.W + x) * a.g.ldx + bn_ci, ok, Bp);
+        ok = ok && (unsigned)(y + bn_tap_dy) < (unsigned)a.g.H && (unsigned)(x + bn_tap_dx) < (unsigned)a.g.W;
+        rb = bload4(rsrcB, ((b * hw + y * a.g.W + x) * a.g.ldx) * 4 + bn_off, ok);
       }
     }
   };
 
   const int st_swz = (kq ^ (r0 & 7)) * 4;  // rows r0 and r0 + 64 share r0 & 7
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, const float4 (&ra)[2], const float4& rb) {
     float* As = lds + buf * (A_FLOATS + B_FLOATS);
     float* Bs = As + A_FLOATS;
     if constexpr (AOP == OP_ROWCONTIG || AOP == OP_IM2COL_M) {
@@ -275,14 +292,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  if (ntiles > 0) {
-    load_tiles(kbeg);
-    store_tiles(0);
-  }
-  __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < ntiles) load_tiles(kbeg + (t + 1) * BK);
+  auto compute = [&](int cur) {
     const float* As = lds + cur * (A_FLOATS + B_FLOATS);
     const float* Bs = As + A_FLOATS;
 #pragma unroll
@@ -305,7 +315,25 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
     }
-    if (t + 1 < ntiles) store_tiles(cur ^ 1);
+  };
+
+  // tile t+1 sits in register set (t+1)&1, tile t+2 in set t&1
+  load_tiles(kbeg, ra0, rb0);
+  store_tiles(0, ra0, rb0);
+  load_tiles(kbeg + BK, ra1, rb1);
+  load_tiles(kbeg + 2 * BK, ra0, rb0);
+  __syncthreads();
+  // Two tiles per trip, no early exit: an odd tile count multiplies one all-zero tile (loads past kend are predicated off).
+  // Straight-line code matters here: with a conditional path around the second half the compiler's s_waitcnt bookkeeping
+  // falls back to vmcnt(0) at the loop head and the second tile in flight is lost.
+  for (int t = 0; t < ntiles; t += 2) {
+    store_tiles(1, ra1, rb1);
+    load_tiles(kbeg + (t + 3) * BK, ra1, rb1);
+    compute(0);
+    __syncthreads();
+    store_tiles(0, ra0, rb0);
+    load_tiles(kbeg + (t + 4) * BK, ra0, rb0);
+    compute(1);
     __syncthreads();
   }
 
@@ -497,6 +525,7 @@ int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, 
   TATT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "tatt_conv_fwd: bad dims");
   TATT_CHECK_ARG(Cin % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)X) & 15) == 0, "tatt_conv_fwd: Cin/ldx must be multiples of 4, X 16B aligned");
   TATT_CHECK_ARG((KH & 1) && (KW & 1), "tatt_conv_fwd: odd kernels only");
+  TATT_CHECK_ARG((long)B * H * W * ldx * 4 < (1L << 31) && (long)Cout * Cin * KH * KW * 4 < (1L << 31), "tatt_conv_fwd: operands must stay below 2 GiB (32-bit buffer offsets)");
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.A = X; a.B = Wt; a.C = Y; a.bias = bias;
@@ -507,6 +536,7 @@ int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, 
   a.accumulate = accumulate; a.relu = relu;
   a.g = ConvGeom{H, W, Cin, KH, KW, KH / 2, KW / 2, (int)ldx};
   a.w_sn = w_sn; a.w_sci = w_sci; a.w_base = w_base; a.w_stap = w_stap;
+  if (w_sci == 1 && (w_sn | w_stap | w_base) % 4 == 0 && (((uintptr_t)Wt) & 15) == 0) return launch<OP_IM2COL, OP_CONVW_P>(a, 1, st);
   return launch<OP_IM2COL, OP_CONVW>(a, 1, st);
 }
 
@@ -555,6 +585,7 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
                     long ldx, long lddy, int splitk, float* workspace, int accumulate, hipStream_t st) {
   TATT_CHECK_ARG(Cin % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)X) & 15) == 0, "tatt_conv_wgrad: Cin/ldx multiples of 4");
   TATT_CHECK_ARG(splitk >= 1 && workspace, "tatt_conv_wgrad: workspace required");
+  TATT_CHECK_ARG((long)B * H * W * ldx * 4 < (1L << 31) && (long)B * H * W * lddy * 4 < (1L << 31), "tatt_conv_wgrad: operands must stay below 2 GiB (32-bit buffer offsets)");
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   const int T = KH * KW;
