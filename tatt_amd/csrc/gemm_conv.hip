@@ -66,6 +66,11 @@ constexpr int BUF_OOB = (int)0x80000000;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, BUF_OOB, 0x00020000);
 }
+// voff: per-lane byte offset (bounds checked), soff: wave-uniform byte offset (added after the check, costs no VALU)
+__device__ __forceinline__ float4 bload4s(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return *reinterpret_cast<float4*>(&v);
+}
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, int byte_off, bool ok) {
   i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? byte_off : BUF_OOB, 0, 0);
   return *reinterpret_cast<float4*>(&v);
@@ -110,7 +115,12 @@ __device__ __forceinline__ void split_pixel(int k0, int off, int H, int W, int& 
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int AOP, int BOP>
+// FAST: every operand is 16-byte granular and tile aligned (checked by fast_ok() on the host).  The loaders then cost a
+// handful of VALU instructions per tile: per-thread byte offsets are computed once, the tile's position is a wave-uniform
+// scalar (buffer_load soffset), predication is a v_cndmask to an out-of-range offset.  This matters more than anything
+// else in the kernel: on gfx950 VALU instructions do not overlap with MFMA on a SIMD (tools/exp_mfma_lds.hip: 180 extra
+// VALU ops per 16-MFMA tile drop 134 TFLOP/s to 82), so loader arithmetic is paid in MFMA issue slots.
+template <int AOP, int BOP, bool FAST>
 __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
   const int tid = threadIdx.x;
@@ -180,11 +190,97 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
     am_off = ((am_tap_dy * a.g.W + am_tap_dx) * a.g.ldx + am_ci) * 4;
   }
 
+  // ---- FAST loader state: constant per-thread byte offsets ----------------------------------------
+  int fa_vo[2] = {BUF_OOB, BUF_OOB}, fa_k[2] = {0, 0}, fa_x[2] = {0, 0}, fb_vo = BUF_OOB, fb_k = 0, fb_x = 0;
+  if constexpr (FAST) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (AOP == OP_STRIDED) {
+        const int m = m0 + r0 + 64 * j;
+        fa_k[j] = kq * 4;
+        if (m < a.M) fa_vo[j] = (int)(((long)m * a.sam + kq * 4) * 4);
+      } else if constexpr (AOP == OP_ROWCONTIG) {
+        const int m = m0 + (tid & 31) * 4;
+        fa_k[j] = (tid >> 5) + 16 * j;
+        if (m < a.M) fa_vo[j] = (int)(((long)fa_k[j] * a.sak + m) * 4);
+      } else if constexpr (AOP == OP_IM2COL) {
+        fa_vo[j] = a_off[j] + kq * 16;
+      } else {  // OP_IM2COL_M
+        fa_k[j] = (tid >> 5) + 16 * j;
+        fa_x[j] = fa_k[j] + am_tap_dx;
+        fa_vo[j] = am_off + fa_k[j] * a.g.ldx * 4;
+      }
+    }
+    if constexpr (BOP == OP_STRIDED) {
+      fb_k = kq * 4;
+      if (n0 + r0 < a.N) fb_vo = (int)(((long)(n0 + r0) * a.sbn + kq * 4) * 4);
+    } else if constexpr (BOP == OP_ROWCONTIG) {
+      const int n = n0 + (tid & 15) * 4;
+      fb_k = tid >> 4;
+      if (n < a.N) fb_vo = (int)(((long)fb_k * a.sbk + n) * 4);
+    } else if constexpr (BOP == OP_CONVW_P) {
+      if (bw_ok) fb_vo = bw_off + kq * 16;
+    } else if constexpr (BOP == OP_IM2COL_N) {
+      fb_k = tid >> 4;
+      fb_x = fb_k + bn_tap_dx;
+      fb_vo = bn_off + fb_k * a.g.ldx * 4;
+    }
+  }
+
   // two register sets: the tiles t+1 and t+2 are in flight while tile t is multiplied (global latency under load is
   // longer than one 16-MFMA tile, a prefetch distance of one tile left the MFMA pipe idle half of the time)
   float4 ra0[2], rb0, ra1[2], rb1;
 
   auto load_tiles = [&](int k0, float4 (&ra)[2], float4& rb) {
+    if constexpr (FAST) {
+      const int k0u = __builtin_amdgcn_readfirstlane(k0);
+      const int lim = kend - k0u;  // valid k in this tile (<= 0 past the end: everything predicated off)
+      // ---- A ----
+      if constexpr (AOP == OP_STRIDED) {
+        const bool p = fa_k[0] < lim;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ra[j] = bload4s(rsrcA, p ? fa_vo[j] : BUF_OOB, k0u * 4);
+      } else if constexpr (AOP == OP_ROWCONTIG) {
+        const int so = k0u * (int)a.sak * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ra[j] = bload4s(rsrcA, fa_k[j] < lim ? fa_vo[j] : BUF_OOB, so);
+      } else if constexpr (AOP == OP_IM2COL) {  // Cin % BK == 0: the whole tile shares one tap
+        const int tap = k0u / a.g.Cin, ci0 = k0u - tap * a.g.Cin, ty = tap / a.g.KW;
+        const int dy = ty - a.g.padH, dx = tap - ty * a.g.KW - a.g.padW;
+        const int delta = ((dy * a.g.W + dx) * a.g.ldx + ci0) * 4;
+        const bool live = lim > 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool ok = live && (unsigned)(a_py[j] + dy) < (unsigned)a.g.H && (unsigned)(a_px[j] + dx) < (unsigned)a.g.W;
+          ra[j] = bload4s(rsrcA, ok ? fa_vo[j] + delta : BUF_OOB, 0);
+        }
+      } else {  // OP_IM2COL_M, W % BK == 0: the tile's 32 pixels share one image row
+        const int hw = a.g.H * a.g.W;
+        const int b = k0u / hw, rem = k0u - b * hw, y = rem / a.g.W, x0 = rem - y * a.g.W;
+        const int spix = k0u * a.g.ldx * 4;
+        const bool yok = am_ok && (unsigned)(y + am_tap_dy) < (unsigned)a.g.H;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool ok = yok && fa_k[j] < lim && (unsigned)(x0 + fa_x[j]) < (unsigned)a.g.W;
+          ra[j] = bload4s(rsrcA, ok ? fa_vo[j] + spix : BUF_OOB, 0);
+        }
+      }
+      // ---- B ----
+      if constexpr (BOP == OP_STRIDED) {
+        rb = bload4s(rsrcB, fb_k < lim ? fb_vo : BUF_OOB, k0u * 4);
+      } else if constexpr (BOP == OP_ROWCONTIG) {
+        rb = bload4s(rsrcB, fb_k < lim ? fb_vo : BUF_OOB, k0u * (int)a.sbk * 4);
+      } else if constexpr (BOP == OP_CONVW_P) {
+        const int tap = k0u / a.g.Cin, ci0 = k0u - tap * a.g.Cin;
+        rb = bload4s(rsrcB, lim > 0 ? fb_vo : BUF_OOB, (tap * (int)a.w_stap + ci0) * 4);
+      } else {  // OP_IM2COL_N
+        const int hw = a.g.H * a.g.W;
+        const int b = k0u / hw, rem = k0u - b * hw, y = rem / a.g.W, x0 = rem - y * a.g.W;
+        const bool ok = bn_ok && fb_k < lim && (unsigned)(y + bn_tap_dy) < (unsigned)a.g.H && (unsigned)(x0 + fb_x) < (unsigned)a.g.W;
+        rb = bload4s(rsrcB, ok ? fb_vo + k0u * a.g.ldx * 4 : BUF_OOB, 0);
+      }
+      return;
+    }
     // ---- A ----
     if constexpr (AOP == OP_STRIDED) {
       int k = k0 + kq * 4;
@@ -454,10 +550,30 @@ __global__ __launch_bounds__(256) void skinny_gather(const float* __restrict__ Z
   for (int c = 0; c < COUT; ++c) dst[c] = accumulate ? dst[c] + acc[c] : acc[c];
 }
 
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+const long GIB2 = 1L << 31;
+
+// Can both operands use the FAST loaders (see gemm_kernel)?  Offsets are 32-bit byte offsets from the operand base.
+template <int AOP, int BOP>
+bool fast_ok(const GemmArgs& a) {
+  bool ok = a.kchunk % BK == 0 && a.K > 0;
+  if (AOP == OP_STRIDED) ok = ok && a.sak == 1 && a.sam % 4 == 0 && a.K % 4 == 0 && al16(a.A) && a.sAb % 4 == 0 && ((long)a.M * a.sam + a.K) * 4 < GIB2;
+  if (AOP == OP_ROWCONTIG) ok = ok && a.sam == 1 && a.sak % 4 == 0 && a.M % 4 == 0 && al16(a.A) && a.sAb % 4 == 0 && ((long)a.K * a.sak + a.M) * 4 < GIB2;
+  if (AOP == OP_IM2COL) ok = ok && a.g.Cin % BK == 0;
+  if (AOP == OP_IM2COL_M) ok = ok && a.g.W % BK == 0;
+  if (BOP == OP_STRIDED) ok = ok && a.sbk == 1 && a.sbn % 4 == 0 && a.K % 4 == 0 && al16(a.B) && a.sBb % 4 == 0 && ((long)a.N * a.sbn + a.K) * 4 < GIB2;
+  if (BOP == OP_ROWCONTIG) ok = ok && a.sbn == 1 && a.sbk % 4 == 0 && a.N % 4 == 0 && al16(a.B) && a.sBb % 4 == 0 && ((long)a.K * a.sbk + a.N) * 4 < GIB2;
+  if (BOP == OP_CONVW) ok = false;
+  if (BOP == OP_CONVW_P) ok = ok && a.g.Cin % BK == 0;
+  if (BOP == OP_IM2COL_N) ok = ok && a.g.W % BK == 0;
+  return ok;
+}
+
 template <int AOP, int BOP>
 int launch(const GemmArgs& a, int batch, hipStream_t st) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch * a.splitk);
-  hipLaunchKernelGGL((gemm_kernel<AOP, BOP>), grid, dim3(NTHR), 0, st, a);
+  if (fast_ok<AOP, BOP>(a)) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true>), grid, dim3(NTHR), 0, st, a);
+  else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, false>), grid, dim3(NTHR), 0, st, a);
   TATT_LAUNCH_CHECK("gemm_kernel");
   return TATT_OK;
 }
@@ -610,8 +726,7 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
     a.g = ConvGeom{H, W, Cout, KH, KW, KH / 2, KW / 2, (int)lddy};
     perm = 3;
     perm_c = Cout;
-    dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), splitk);
-    hipLaunchKernelGGL((gemm_kernel<OP_ROWCONTIG, OP_IM2COL_N>), grid, dim3(NTHR), 0, st, a);
+    if (int rc = launch<OP_ROWCONTIG, OP_IM2COL_N>(a, 1, st)) return rc;
   } else if (Cout <= 64 && lddy % 4 == 0 && (((uintptr_t)dY) & 15) == 0) {
     // Cout <= 64 fits ONE 64-wide N tile: put (tap,ci) on the 128-wide M side so that no MFMA rows are padding
     // (with Cout on M a 64-channel conv would fill only half of every 128-row tile).
@@ -622,14 +737,11 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
     a.ldc = a.N;
     a.sCz = (long)a.M * a.N;
     perm = 2;
-    dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), splitk);
-    hipLaunchKernelGGL((gemm_kernel<OP_IM2COL_M, OP_ROWCONTIG>), grid, dim3(NTHR), 0, st, a);
+    if (int rc = launch<OP_IM2COL_M, OP_ROWCONTIG>(a, 1, st)) return rc;
   } else {
     // the kernel treats splitk>1 as "write raw slabs"; with splitk==1 it applies bias/accumulate (none set): same result.
-    dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), splitk);
-    hipLaunchKernelGGL((gemm_kernel<OP_ROWCONTIG, OP_IM2COL_N>), grid, dim3(NTHR), 0, st, a);
+    if (int rc = launch<OP_ROWCONTIG, OP_IM2COL_N>(a, 1, st)) return rc;
   }
-  TATT_LAUNCH_CHECK("conv_wgrad");
   long tot = (long)a.M * a.N;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, workspace, tot, splitk, dW, (const float*)nullptr,
                      a.M, a.N, (long)a.N, accumulate, 0, perm, perm_c, T, 0L);

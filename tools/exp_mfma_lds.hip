@@ -4,7 +4,7 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BN = 64, BK = 32;
-template <bool BARRIER, bool DSWRITE, bool GLOAD, int DIST>
+template <bool BARRIER, bool DSWRITE, bool GLOAD, int DIST, int NVALU = 0>
 __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ X, float* out, int ntiles) {
   __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5, wm = wave & 3, wn = wave >> 2;
@@ -31,6 +31,11 @@ __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ X, float* 
       for (int j = 0; j < 3; ++j) *reinterpret_cast<float4*>(b + (r0 + 64 * j) * BK + sw) = rr[j];
     }
   };
+  unsigned junk = tid;
+  auto valu = [&]() {
+#pragma unroll
+    for (int i = 0; i < NVALU; ++i) junk = junk * 1664525u + (unsigned)i + (junk >> 7);  // 3 dependent VALU ops each
+  };
   auto compute = [&](int buf) {
     const float* As = lds + buf * (BM + BN) * BK;
     const float* Bs = As + BM * BK;
@@ -46,26 +51,32 @@ __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ X, float* 
   };
   if (DIST == 2) { gload(1, r[1]); gload(2, r[0]); } else { gload(1, r[1]); }
   for (int t = 0; t < ntiles; t += 2) {
+    valu();
     if (DIST == 2) { dswrite(1, r[1]); gload(t + 3, r[1]); compute(0); }
     else { compute(0); dswrite(1, r[1]); gload(t + 2, r[0]); }
     if (BARRIER) __syncthreads();
+    valu();
     if (DIST == 2) { dswrite(0, r[0]); gload(t + 4, r[0]); compute(1); }
     else { compute(1); dswrite(0, r[0]); gload(t + 3, r[1]); }
     if (BARRIER) __syncthreads();
   }
   float s = 0.f;
   for (int i = 0; i < 16; ++i) s += acc[i];
-  out[blockIdx.x * 512 + tid] = s + r[0][0].x + r[1][2].y;
+  out[blockIdx.x * 512 + tid] = s + r[0][0].x + r[1][2].y + (float)junk;
 }
-template <bool BARRIER, bool DSWRITE, bool GLOAD, int DIST>
-void run(const char* name, const float* X, float* d, int blocks) {
+template <bool BARRIER, bool DSWRITE, bool GLOAD, int DIST, int NVALU = 0>
+void run(const char* name, const float* X, float* d, int blocks, bool SHORT = false) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   const int ntiles = 18 * 20;
-  hipLaunchKernelGGL((k<BARRIER, DSWRITE, GLOAD, DIST>), dim3(blocks), dim3(512), 0, 0, X, d, 18);
+  hipLaunchKernelGGL((k<BARRIER, DSWRITE, GLOAD, DIST, NVALU>), dim3(blocks), dim3(512), 0, 0, X, d, 18);
   (void)hipEventRecord(e0);
-  hipLaunchKernelGGL((k<BARRIER, DSWRITE, GLOAD, DIST>), dim3(blocks), dim3(512), 0, 0, X, d, ntiles);
+  if (SHORT) {
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k<BARRIER, DSWRITE, GLOAD, DIST, NVALU>), dim3(blocks), dim3(512), 0, 0, X, d, 18);
+  } else {
+    hipLaunchKernelGGL((k<BARRIER, DSWRITE, GLOAD, DIST, NVALU>), dim3(blocks), dim3(512), 0, 0, X, d, ntiles);
+  }
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms;
@@ -84,6 +95,12 @@ int main() {
     run<true, true, false, 1>("+ ds_write", X, d, blocks);
     run<true, true, true, 1>("+ global loads, dist 1", X, d, blocks);
     run<true, true, true, 2>("+ global loads, dist 2", X, d, blocks);
+    run<true, true, true, 2>("same, 20 launches of 18 tiles", X, d, blocks, true);
+    run<true, true, true, 2, 10>("dist 2 + 30 VALU/tile", X, d, blocks);
+    run<true, true, true, 2, 20>("dist 2 + 60 VALU/tile", X, d, blocks);
+    run<true, true, true, 2, 40>("dist 2 + 120 VALU/tile", X, d, blocks);
+    run<true, true, true, 2, 60>("dist 2 + 180 VALU/tile", X, d, blocks);
+    run<false, false, false, 1>("lds+mfma only, 20 launches of 18 tiles", X, d, blocks, true);
   }
   return 0;
 }
