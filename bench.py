@@ -27,28 +27,38 @@ FLOP_PER_IMAGE_TRAIN = 7.70e9        # fwd+bwd, pixel+gradient loss
 PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 matrix peak
 
 
-def conv_roofline(L, B, iters=30):
-    """Dominant kernel = the NHWC implicit-GEMM conv (SRB shape 3x3, 64->64, 16x64 maps): 22 of its launches per
-    step.  Timed with events on the launch stream; algorithmic FLOPs = 2 * pixels * Cout * 9*Cin."""
-    x = torch.randn(B, 16, 64, 64, device="cuda")
-    w = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
-    b = torch.randn(64, device="cuda")
-    y = torch.empty(B, 16, 64, 64, device="cuda")
-    args = (x, w, b, y, B, 16, 64, 64, 64, 3, 3, 64, 64, 64 * 9, 9, 0, 1, 0, 0)
-    for _ in range(5):
-        L.conv_fwd(*args)
+def conv_roofline(L, B, iters=10):
+    """Dominant kernel = gemm_kernel<OP_IM2COL, OP_CONVW_P, FAST>: the NHWC implicit-GEMM convolution (forward and
+    dgrad) over per-step packed weights, 34 launches per training step.  Replays exactly that per-step launch mix
+    (22 x SRB/block7 3x3 64->64 on [B,16,64], the 64<->256 up-sampling conv and its dgrad, 10 STN-head convs) so that
+    the average launch time is comparable with the rocprofv3 --stats average of the same symbol.  Timed with events
+    on the launch stream; algorithmic FLOPs per launch = 2 * pixels * Cout * KH*KW*Cin."""
+    mix = [(16, 64, 64, 64)] * 22 + [(16, 64, 64, 256), (16, 64, 256, 64)]
+    stn = [(16, 32, 32, 64), (8, 16, 64, 128), (4, 8, 128, 256), (2, 4, 256, 256), (2, 2, 256, 256)]
+    mix += stn + [(h, w, co, ci) for h, w, ci, co in stn]                     # forward + dgrad of the STN stages 1..5
+    calls, flops = [], 0.0
+    for H, W, Cin, Cout in mix:
+        x = torch.randn(B, H, W, Cin, device="cuda")
+        wf = torch.randn(Cout * 9 * Cin, device="cuda") * 0.05
+        b = torch.randn(Cout, device="cuda")
+        y = torch.empty(B, H, W, Cout, device="cuda")
+        calls.append((x, wf, b, y, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 9 * Cin, 1, 0, Cin, 0, 0))
+        flops += 2.0 * B * H * W * Cout * 9 * Cin
+    for c in calls:
+        L.conv_fwd(*c)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        L.conv_fwd(*args)
+        for c in calls:
+            L.conv_fwd(*c)
     e1.record()
     e1.synchronize()
-    dt = e0.elapsed_time(e1) / iters * 1e-3
-    flops = 2.0 * B * 16 * 64 * 64 * 9 * 64
-    ach = flops / dt / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW> conv3x3 64->64 [B,16,64]", "achieved": round(ach, 2),
-            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "launch_us": round(dt * 1e6, 2), "flop_per_launch": flops}
+    dt = e0.elapsed_time(e1) / (iters * len(calls)) * 1e-3
+    fl = flops / len(calls)
+    ach = fl / dt / 1e12
+    return {"bound": "mfma", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST> (3x3 conv fwd+dgrad, per-step mix of %d launches)" % len(calls),
+            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": None, "launch_us": round(dt * 1e6, 2), "flop_per_launch": fl, "launches_per_step": len(calls)}
 
 
 def cpu_baseline(state, B, K, steps=2):

@@ -76,6 +76,13 @@ int tatt_gru32_bwd(const float* dout, const float* out, const float* save, const
 /* ---- recurrent positional encoding GRU(1024 -> 2x512) gates (model/transformer_v2.py:177,:215-221) -------- */
 int tatt_rpe_gate_fwd(const float* gi, const float* gh, const float* bhh_f, const float* bhh_b, const float* hprev, float* hout, float* qp, int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t stream);
 int tatt_rpe_gate_bwd(const float* gi, const float* gh, const float* bhh_f, const float* bhh_b, const float* hprev, const float* dqp, float* carry, float* dgh, float* dgi_sum, int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t stream);
+/* One launch per recurrence step of the same GRU (nn.GRU at model/transformer_v2.py:177 run over the batch axis, :215-221):
+ * h_{s+1} = GRU(x, h_s) with gh = h_s W_hh^T computed in the kernel (fwd), and the BPTT step that first adds
+ * dgh_{s+1} W_hh to the carried d*z and then differentiates the gates of step s (bwd; whhT from tatt_rpe_whh_transpose,
+ * dgh_next = NULL on the first call, s = B-1). */
+int tatt_rpe_step_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, const float* hprev, float* hout, float* gh_out, float* qp, int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t stream);
+int tatt_rpe_whh_transpose(const float* whh_f, const float* whh_b, float* whhT, hipStream_t stream);
+int tatt_rpe_step_bwd(const float* gi, const float* gh, const float* bhh_f, const float* bhh_b, const float* hprev, const float* dqp, float* carry, const float* dgh_next, float* dgh_out, float* dgi_sum, const float* whhT, int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t stream);
 int tatt_rpe_gather_x(const float* init_factor, float* x, hipStream_t stream);
 int tatt_rpe_scatter_dx(const float* dx, float* dinit, int accumulate, hipStream_t stream);
 

@@ -211,9 +211,197 @@ __global__ void rpe_scatter_dx(const float* __restrict__ dx, float* __restrict__
   dinit[o] = accumulate ? dinit[o] + dx[i] : dx[i];
 }
 
+// ---- fused RPE steps ---------------------------------------------------------------------------------------------
+// The recurrence over the batch axis is a chain of 2*B dependent [64,512]x[512,1536] products: latency, not FLOPs.  One
+// launch per step does the product, the cross-wave reduction and the gate math (instead of split-K GEMM + reduce + gate
+// kernel), with v_mfma_f32_16x16x4_f32 tiles fed straight from global memory: lane (i = l&15, q = l>>4) loads float4s of
+// row i at k = kbase + 16e + 4q (the four q-lanes of a row cover one 64-byte line per load), A and B with the same k
+// order, so no LDS staging is needed.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void mfma4(f32x4& acc, const float4& a, const float4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+}
+
+// forward step: block (jb, dir) owns hidden units j0..j0+3 (12 gate columns, padded to one 16-wide tile) for all 64 rows;
+// the four waves split K = 512.  Writes h_{s+1}, query_pos and the raw gh (no bias) that the backward pass re-reads.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rpe_step_fwd(const float* __restrict__ gi, const float* __restrict__ whh_f,
+                                                    const float* __restrict__ whh_b, const float* __restrict__ bhh_f,
+                                                    const float* __restrict__ bhh_b, const float* __restrict__ hprev,
+                                                    float* __restrict__ hout, float* __restrict__ gh_out, float* __restrict__ qp,
+                                                    int s, int B, long dir_stride_gh, long dir_stride_h) {
+  __shared__ float red[4][RW][17];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int dir = blockIdx.y, j0 = blockIdx.x * 4;
+  const float* W = dir ? whh_b : whh_f;
+  const float* hp = hprev + dir * dir_stride_h;
+  const int kbase = wv * 128 + q * 4;  // step e: k = kbase + 16e (+c): the 4 q-lanes of a row read one 64-byte line
+  float4 bf[8], af[4][8];
+  {
+    const bool on = i < 12;
+    const float* pb = W + (long)((i >> 2) * RH + j0 + (i & 3)) * RH + kbase;
+    const float* pa = hp + (long)i * RH + kbase;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {  // issued in the order the MFMAs consume them
+      bf[e] = on ? *reinterpret_cast<const float4*>(pb + 16 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) af[mt][e] = *reinterpret_cast<const float4*>(pa + (long)mt * 16 * RH + 16 * e);
+    }
+  }
+  // gate operands of this thread's (row, unit): issued before the MFMAs so that their latency hides behind them
+  const int w = tid >> 2, jj = tid & 3, j = j0 + jj;
+  const float* g_i = gi + ((long)dir * RW + w) * 3 * RH;
+  const float* bh = dir ? bhh_b : bhh_f;
+  const float gir = g_i[j], giz = g_i[RH + j], gin = g_i[2 * RH + j];
+  const float br = bh[j], bz = bh[RH + j], bn = bh[2 * RH + j];
+  const float hpv = hp[(long)w * RH + j];
+  f32x4 acc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_sched_barrier(0);  // every load above is issued before the first MFMA: the step is pure latency
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) mfma4(acc[mt], af[mt][e], bf[e]);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv][mt * 16 + 4 * q + r][i] = acc[mt][r];
+  __syncthreads();
+  float gh[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) gh[g] = (red[0][w][g * 4 + jj] + red[1][w][g * 4 + jj]) + (red[2][w][g * 4 + jj] + red[3][w][g * 4 + jj]);
+  const float r = sigmoidf_(gir + gh[0] + br);
+  const float z = sigmoidf_(giz + gh[1] + bz);
+  const float n = tanhf_(gin + r * (gh[2] + bn));
+  const float h = (1.f - z) * n + z * hpv;
+  hout[dir * dir_stride_h + (long)w * RH + j] = h;
+  float* go = gh_out + dir * dir_stride_gh + (long)w * 3 * RH;
+  go[j] = gh[0];
+  go[RH + j] = gh[1];
+  go[2 * RH + j] = gh[2];
+  const int tt = dir ? B - 1 - s : s;
+  const int f = dir * RH + j;
+  qp[(((long)tt * 16 + (f >> 6)) * RW + w) * 64 + (f & 63)] = h;
+}
+
+// whhT[dir][j][i] = whh_dir[i][j]  ([1536][512] -> [512][1536]); once per backward pass
+__global__ void rpe_whh_transpose(const float* __restrict__ whh_f, const float* __restrict__ whh_b, float* __restrict__ whhT) {
+  __shared__ float t[32][33];
+  const float* W = blockIdx.z ? whh_b : whh_f;
+  float* O = whhT + (long)blockIdx.z * RH * 3 * RH;
+  const int i0 = blockIdx.y * 32, jb = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) t[r][tx] = W[(long)(i0 + r) * RH + jb + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) O[(long)(jb + r) * 3 * RH + i0 + tx] = t[tx][r];
+}
+
+// backward step s: block (jb, mh, dir) owns rows mh*32..+31, units jb*16..+15.  First the recurrent gradient arriving from
+// step s+1, carry = d_{s+1} z_{s+1} (left in `carry` by that step) + dgh_{s+1} W_hh (K = 1536 split over the four waves,
+// three 128-wide chunks each), then the gate backward of step s for the same (row, unit) elements.  dgh_next == nullptr
+// for the first (last-in-time) step.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rpe_step_bwd(const float* __restrict__ gi, const float* __restrict__ gh,
+                                                    const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
+                                                    const float* __restrict__ hprev, const float* __restrict__ dqp,
+                                                    float* __restrict__ carry, const float* __restrict__ dgh_next,
+                                                    float* __restrict__ dgh_out, float* __restrict__ dgi_sum,
+                                                    const float* __restrict__ whhT, int s, int B, long dir_stride_gh,
+                                                    long dir_stride_h) {
+  __shared__ float red[4][32][17];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int jb = blockIdx.x, mh = blockIdx.y, dir = blockIdx.z;
+  if (dgh_next) {
+    const float* A = dgh_next + dir * dir_stride_gh + (long)(mh * 32 + i) * 3 * RH + wv * 384 + q * 4;
+    const float* Bt = whhT + ((long)dir * RH + jb * 16 + i) * 3 * RH + wv * 384 + q * 4;
+    float4 af[3][2][8], bf[3][8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {  // issued in the order the MFMAs consume them
+        bf[c][e] = *reinterpret_cast<const float4*>(Bt + c * 128 + 16 * e);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) af[c][mt][e] = *reinterpret_cast<const float4*>(A + (long)mt * 16 * 3 * RH + c * 128 + 16 * e);
+      }
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    __builtin_amdgcn_sched_barrier(0);  // all 72 loads in flight before the first MFMA: the step is pure latency
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) mfma4(acc[mt], af[c][mt][e], bf[c][e]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wv][mt * 16 + 4 * q + r][i] = acc[mt][r];
+  }
+  __syncthreads();
+  const float* bh = dir ? bhh_b : bhh_f;
+  const int tt = dir ? B - 1 - s : s;
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int e = tid + 256 * h2, wl = e >> 4, jj = e & 15;
+    const int w = mh * 32 + wl, j = jb * 16 + jj;
+    const long ci = ((long)dir * RW + w) * RH + j;
+    float c = carry[ci];
+    if (dgh_next) c += (red[0][wl][jj] + red[1][wl][jj]) + (red[2][wl][jj] + red[3][wl][jj]);
+    const float* g_i = gi + ((long)dir * RW + w) * 3 * RH;
+    const float* g_h = gh + dir * dir_stride_gh + (long)w * 3 * RH;
+    const float hp = hprev[dir * dir_stride_h + (long)w * RH + j];
+    const float ghn = g_h[2 * RH + j] + bh[2 * RH + j];
+    const float r = sigmoidf_(g_i[j] + g_h[j] + bh[j]);
+    const float z = sigmoidf_(g_i[RH + j] + g_h[RH + j] + bh[RH + j]);
+    const float n = tanhf_(g_i[2 * RH + j] + r * ghn);
+    const int f = dir * RH + j;
+    const float d = c + dqp[(((long)tt * 16 + (f >> 6)) * RW + w) * 64 + (f & 63)];
+    const float dn = d * (1.f - z) * (1.f - n * n);
+    const float dz = d * (hp - n) * z * (1.f - z);
+    const float dr = dn * ghn * r * (1.f - r);
+    float* o = dgh_out + dir * dir_stride_gh + (long)w * 3 * RH;
+    o[j] = dr;
+    o[RH + j] = dz;
+    o[2 * RH + j] = dn * r;
+    float* gs = dgi_sum + ((long)dir * RW + w) * 3 * RH;
+    gs[j] += dr;
+    gs[RH + j] += dz;
+    gs[2 * RH + j] += dn;
+    carry[ci] = d * z;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int tatt_rpe_step_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b,
+                      const float* hprev, float* hout, float* gh_out, float* qp, int s, int B, long dir_stride_gh,
+                      long dir_stride_h, hipStream_t st) {
+  TATT_CHECK_ARG(gi && whh_f && whh_b && hprev && hout && gh_out && qp && s >= 0 && s < B, "tatt_rpe_step_fwd: bad arguments");
+  hipLaunchKernelGGL(rpe_step_fwd, dim3(RH / 4, 2), dim3(256), 0, st, gi, whh_f, whh_b, bhh_f, bhh_b, hprev, hout, gh_out, qp, s, B,
+                     dir_stride_gh, dir_stride_h);
+  TATT_LAUNCH_CHECK("rpe_step_fwd");
+  return TATT_OK;
+}
+
+int tatt_rpe_whh_transpose(const float* whh_f, const float* whh_b, float* whhT, hipStream_t st) {
+  hipLaunchKernelGGL(rpe_whh_transpose, dim3(RH / 32, 3 * RH / 32, 2), dim3(256), 0, st, whh_f, whh_b, whhT);
+  TATT_LAUNCH_CHECK("rpe_whh_transpose");
+  return TATT_OK;
+}
+
+int tatt_rpe_step_bwd(const float* gi, const float* gh, const float* bhh_f, const float* bhh_b, const float* hprev,
+                      const float* dqp, float* carry, const float* dgh_next, float* dgh_out, float* dgi_sum, const float* whhT,
+                      int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t st) {
+  TATT_CHECK_ARG(gi && gh && hprev && dqp && carry && dgh_out && dgi_sum && whhT && s >= 0 && s < B, "tatt_rpe_step_bwd: bad arguments");
+  hipLaunchKernelGGL(rpe_step_bwd, dim3(RH / 16, 2, 2), dim3(256), 0, st, gi, gh, bhh_f, bhh_b, hprev, dqp, carry, dgh_next, dgh_out,
+                     dgi_sum, whhT, s, B, dir_stride_gh, dir_stride_h);
+  TATT_LAUNCH_CHECK("rpe_step_bwd");
+  return TATT_OK;
+}
 
 int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* out,
                    float* save, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride, hipStream_t st) {

@@ -388,13 +388,10 @@ class Engine:
         gh_all = self.new(2, B, 64, 1536)
         qp = self.new(R0, 64)
         whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
-        wdiff = (whh_b.data_ptr() - whh_f.data_ptr()) // 4
         dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
-        for s in range(B):
-            # [64,512] x [512,1536] per direction: split K 4 ways so that the step fills the chip (192 workgroups)
-            L.gemm(hstep[0, s], whh_f, gh_all[0, s], None, 64, 1536, 512, 512, 1, 512, 1, 1536, 2, dsh, wdiff, dsg, 0, 0, 4, self.ws)
-            L.rpe_gate_fwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], hstep[0, s + 1], qp,
-                           s, B, dsg, dsh)
+        for s in range(B):      # one fused launch per step: h_s W_hh^T, gates, h_{s+1}, query_pos (tatt_rpe_step_fwd)
+            L.rpe_step_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], hstep[0, s + 1],
+                           gh_all[0, s], qp, s, B, dsg, dsh)
         # encoder layer (input doubled, model/transformer_v2.py:273)
         e = tr + "encoder.layers.0."
         src2, qk = self.new(Rt, 64), self.new(Rt, 64)
@@ -565,16 +562,15 @@ class Engine:
         # recurrent positional encoding, BPTT over the batch axis
         g = tr + "gru_encoding."
         whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
-        wdiff = (whh_b.data_ptr() - whh_f.data_ptr()) // 4
         dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
         carry = self.zeros(2, 64, 512)
         dgi_sum = self.zeros(2, 64, 1536)
         dgh_all = self.new(2, B, 64, 1536)
+        whhT = self.new(2, 512, 1536)
+        L.rpe_whh_transpose(whh_f, whh_b, whhT)
         for s in reversed(range(B)):
-            L.rpe_gate_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
-                           dgh_all[0, s], dgi_sum, s, B, dsg, dsh)
-            if s > 0:
-                L.gemm(dgh_all[0, s], whh_f, carry, None, 64, 512, 1536, 1536, 1, 1, 512, 512, 2, dsg, wdiff, 64 * 512, 1, 0, 8, self.ws)
+            L.rpe_step_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
+                           dgh_all[0, s + 1] if s + 1 < B else None, dgh_all[0, s], dgi_sum, whhT, s, B, dsg, dsh)
         dxg = self.new(64, 1024)
         for dd, sfx in enumerate(["", "_reverse"]):
             self.linear_dw(dgh_all[dd], hstep[dd], G[g + "weight_hh_l0" + sfx], 64 * B, 1536, 512)

@@ -255,6 +255,47 @@ def test_gru32_fwd_bwd(vertical):
     close(dx.view(B, H, W, 64), x.grad, 5e-5, "gru dx")
 
 
+def test_rpe_fused_steps_vs_torch_gru():
+    """tatt_rpe_step_fwd / _bwd (one launch per step of the GRU(1024 -> 2x512) that runs over the batch axis with the
+    same input at every step) against nn.GRU autograd in fp64."""
+    B = 5
+    torch.manual_seed(0)
+    gru = torch.nn.GRU(1024, 512, bidirectional=True).double()
+    x = rnd(64, 1024).double()
+    out, _ = gru(x.unsqueeze(0).expand(B, 64, 1024))
+    dout = rnd(B, 64, 1024, seed=3).double()
+    out.backward(dout)
+    sfx = ["", "_reverse"]
+    W = {n: cu(p_.detach().float()) for n, p_ in gru.named_parameters()}
+    gi = torch.stack([x @ getattr(gru, "weight_ih_l0" + d).detach().T + getattr(gru, "bias_ih_l0" + d).detach() for d in sfx])
+    gi = cu(gi.float())
+    hstep = torch.zeros(2, B + 1, 64, 512, device="cuda")
+    gh_all = torch.empty(2, B, 64, 1536, device="cuda")
+    qp = torch.empty(B, 16, 64, 64, device="cuda")
+    dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
+    bf, bb = W["bias_hh_l0"], W["bias_hh_l0_reverse"]
+    for s_ in range(B):
+        L().rpe_step_fwd(gi, W["weight_hh_l0"], W["weight_hh_l0_reverse"], bf, bb, hstep[0, s_], hstep[0, s_ + 1], gh_all[0, s_], qp,
+                         s_, B, dsg, dsh)
+    close(qp.permute(0, 2, 1, 3).reshape(B, 64, 1024), out.detach(), what="rpe out")
+    dqp = cu(dout.float().view(B, 64, 16, 64).permute(0, 2, 1, 3))
+    carry = torch.zeros(2, 64, 512, device="cuda")
+    dgi_sum = torch.zeros(2, 64, 1536, device="cuda")
+    dgh_all = torch.empty(2, B, 64, 1536, device="cuda")
+    whhT = torch.empty(2, 512, 1536, device="cuda")
+    L().rpe_whh_transpose(W["weight_hh_l0"], W["weight_hh_l0_reverse"], whhT)
+    assert torch.equal(whhT[1], W["weight_hh_l0_reverse"].T)
+    for s_ in reversed(range(B)):
+        L().rpe_step_bwd(gi, gh_all[0, s_], bf, bb, hstep[0, s_], dqp, carry, dgh_all[0, s_ + 1] if s_ + 1 < B else None,
+                         dgh_all[0, s_], dgi_sum, whhT, s_, B, dsg, dsh)
+    for d, sx in enumerate(sfx):
+        close(dgi_sum[d].sum(0), getattr(gru, "bias_ih_l0" + sx).grad, what="db_ih" + sx)
+        close(dgi_sum[d].T @ cu(x.float()), getattr(gru, "weight_ih_l0" + sx).grad, what="dW_ih" + sx)
+        close(dgh_all[d].sum((0, 1)), getattr(gru, "bias_hh_l0" + sx).grad, what="db_hh" + sx)
+        dwhh = sum(dgh_all[d, s_].T @ hstep[d, s_] for s_ in range(B))
+        close(dwhh, getattr(gru, "weight_hh_l0" + sx).grad, what="dW_hh" + sx)
+
+
 @pytest.mark.parametrize("Lq,p", [(1024, 0.0), (26, 0.0), (1024, 0.1), (100, 0.1)])
 def test_attention_fwd_bwd(Lq, p):
     B = 3

@@ -91,3 +91,12 @@ for sk in (32, 64):
 for sk in (64, 128, 256):
     t(f"conv9x9 64->4 wgrad sk={sk}", lambda: L.conv_wgrad(up, pre, dw994, B, 32, 128, 64, 4, 9, 9, 64, 4, sk, ws, 1), 2 * 4 * R * 4 * 5184, 4 * R * 272)
 t("pixshuf_mish fwd", lambda: L.pixshuf_mish_fwd(y256, up, B, 16, 64, 64), 0, R * 2048)
+
+# fused RPE steps
+gi_, whf, whb, bhf, bhb = rnd(2, 64, 1536), rnd(1536, 512) * 0.05, rnd(1536, 512) * 0.05, rnd(1536), rnd(1536)
+hst, gha, qp_ = torch.zeros(2, B + 1, 64, 512, device="cuda"), rnd(2, B, 64, 1536), rnd(B, 16, 64, 64)
+dsh_, dsg_ = (B + 1) * 64 * 512, B * 64 * 1536
+t("rpe_step_fwd (fused)", lambda: L.rpe_step_fwd(gi_, whf, whb, bhf, bhb, hst[0, 3], hst[0, 4], gha[0, 3], qp_, 3, B, dsg_, dsh_), 2 * 2 * 64 * 1536 * 512, 0)
+whT, car, dga, dgs = rnd(2, 512, 1536), rnd(2, 64, 512), rnd(2, B, 64, 1536), torch.zeros(2, 64, 1536, device="cuda")
+t("rpe_step_bwd (fused)", lambda: L.rpe_step_bwd(gi_, gha[0, 3], bhf, bhb, hst[0, 3], qp_, car, dga[0, 4], dga[0, 3], dgs, whT, 3, B, dsg_, dsh_), 2 * 2 * 64 * 1536 * 512, 0)
+t("rpe_whh_transpose", lambda: L.rpe_whh_transpose(whf, whb, whT), 0, 2 * 1536 * 512 * 8)
