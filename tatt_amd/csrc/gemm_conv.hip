@@ -227,13 +227,30 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
     }
   }
 
+  // wave-uniform position of the next tile to load (FAST)
+  int t_k0 = kbeg, t_tap = 0, t_ci0 = 0, t_ty = 0, t_tx = 0, t_y = 0, t_x0 = 0;
+  if constexpr (FAST && (AOP == OP_IM2COL || BOP == OP_CONVW_P)) {
+    t_tap = kbeg / a.g.Cin;
+    t_ci0 = kbeg - t_tap * a.g.Cin;
+    t_ty = t_tap / a.g.KW;
+    t_tx = t_tap - t_ty * a.g.KW;
+  }
+  if constexpr (FAST && (AOP == OP_IM2COL_M || BOP == OP_IM2COL_N)) {
+    const int rem = kbeg % (a.g.H * a.g.W);
+    t_y = rem / a.g.W;
+    t_x0 = rem - t_y * a.g.W;
+  }
+
   // two register sets: the tiles t+1 and t+2 are in flight while tile t is multiplied (global latency under load is
   // longer than one 16-MFMA tile, a prefetch distance of one tile left the MFMA pipe idle half of the time)
   float4 ra0[2], rb0, ra1[2], rb1;
 
   auto load_tiles = [&](int k0, float4 (&ra)[2], float4& rb) {
     if constexpr (FAST) {
-      const int k0u = __builtin_amdgcn_readfirstlane(k0);
+      // Tiles are requested in order (kbeg, kbeg+BK, ...), so the tile's tap / pixel coordinates are wave-uniform state
+      // advanced with a few scalar adds and selects; divisions here would cost ~100 SALU instructions per tile, which on
+      // this machine is as good as lost MFMA issue time.
+      const int k0u = t_k0;
       const int lim = kend - k0u;  // valid k in this tile (<= 0 past the end: everything predicated off)
       // ---- A ----
       if constexpr (AOP == OP_STRIDED) {
@@ -245,9 +262,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) ra[j] = bload4s(rsrcA, fa_k[j] < lim ? fa_vo[j] : BUF_OOB, so);
       } else if constexpr (AOP == OP_IM2COL) {  // Cin % BK == 0: the whole tile shares one tap
-        const int tap = k0u / a.g.Cin, ci0 = k0u - tap * a.g.Cin, ty = tap / a.g.KW;
-        const int dy = ty - a.g.padH, dx = tap - ty * a.g.KW - a.g.padW;
-        const int delta = ((dy * a.g.W + dx) * a.g.ldx + ci0) * 4;
+        const int dy = t_ty - a.g.padH, dx = t_tx - a.g.padW;
+        const int delta = ((dy * a.g.W + dx) * a.g.ldx + t_ci0) * 4;
         const bool live = lim > 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -255,8 +271,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
           ra[j] = bload4s(rsrcA, ok ? fa_vo[j] + delta : BUF_OOB, 0);
         }
       } else {  // OP_IM2COL_M, W % BK == 0: the tile's 32 pixels share one image row
-        const int hw = a.g.H * a.g.W;
-        const int b = k0u / hw, rem = k0u - b * hw, y = rem / a.g.W, x0 = rem - y * a.g.W;
+        const int y = t_y, x0 = t_x0;
         const int spix = k0u * a.g.ldx * 4;
         const bool yok = am_ok && (unsigned)(y + am_tap_dy) < (unsigned)a.g.H;
 #pragma unroll
@@ -271,13 +286,31 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
       } else if constexpr (BOP == OP_ROWCONTIG) {
         rb = bload4s(rsrcB, fb_k < lim ? fb_vo : BUF_OOB, k0u * (int)a.sbk * 4);
       } else if constexpr (BOP == OP_CONVW_P) {
-        const int tap = k0u / a.g.Cin, ci0 = k0u - tap * a.g.Cin;
-        rb = bload4s(rsrcB, lim > 0 ? fb_vo : BUF_OOB, (tap * (int)a.w_stap + ci0) * 4);
+        rb = bload4s(rsrcB, lim > 0 ? fb_vo : BUF_OOB, (t_tap * (int)a.w_stap + t_ci0) * 4);
       } else {  // OP_IM2COL_N
-        const int hw = a.g.H * a.g.W;
-        const int b = k0u / hw, rem = k0u - b * hw, y = rem / a.g.W, x0 = rem - y * a.g.W;
+        const int y = t_y, x0 = t_x0;
         const bool ok = bn_ok && fb_k < lim && (unsigned)(y + bn_tap_dy) < (unsigned)a.g.H && (unsigned)(x0 + fb_x) < (unsigned)a.g.W;
         rb = bload4s(rsrcB, ok ? fb_vo + k0u * a.g.ldx * 4 : BUF_OOB, 0);
+      }
+      // ---- advance to the next tile ----
+      t_k0 += BK;
+      if constexpr (AOP == OP_IM2COL || BOP == OP_CONVW_P) {
+        t_ci0 += BK;
+        if (t_ci0 >= a.g.Cin) {
+          t_ci0 = 0;
+          ++t_tap;
+          if (++t_tx == a.g.KW) {
+            t_tx = 0;
+            ++t_ty;
+          }
+        }
+      }
+      if constexpr (AOP == OP_IM2COL_M || BOP == OP_IM2COL_N) {
+        t_x0 += BK;
+        if (t_x0 >= a.g.W) {
+          t_x0 = 0;
+          if (++t_y == a.g.H) t_y = 0;
+        }
       }
       return;
     }
