@@ -3,20 +3,24 @@
 // No LDS staging: for v_mfma_f32_32x32x2_f32 lane (i = l&31, h = l>>5) supplies A[i][k=h] and B[k=h][i], which for row-major
 // [R, C] operands is exactly "lanes 0-31 read 32 consecutive floats of row r, lanes 32-63 of row r+1": coalesced 128-B
 // loads straight into the MFMA operands.  Each wave streams its own row range (deep unroll keeps loads in flight), the
-// four waves of a block are summed through LDS, every block writes one partial slab, a second kernel sums the slabs
-// in a fixed order (deterministic; no atomics).  The bias gradient rides along on the already loaded dY fragments.
+// eight waves of a block are summed by a three-level tree through LDS, every block (at most one per CU, so at most 256
+// slabs to write and re-read) writes one partial slab, a second kernel sums the slabs in a fixed order (deterministic;
+// no atomics).  The bias gradient rides along on the already loaded dY fragments.
 #include "common.h"
 
 namespace {
 
+constexpr int TN_WAVES = 8, TN_MAXBLK = 256;
+
 template <int MT, int NT>
-__global__ __launch_bounds__(256) void tn_small_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx,
+__global__ __launch_bounds__(TN_WAVES * 64) void tn_small_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx,
                                                        int M, int N, int R, int rows_per_blk, float* __restrict__ slabs) {
-  __shared__ float red[MT * 32 * NT * 32 + MT * 32];
+  constexpr int SLOT = MT * 32 * NT * 32 + MT * 32;  // one wave's partial: the MxN tile + the bias column sums
+  __shared__ float red[(TN_WAVES / 2) * SLOT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int rb = blockIdx.x * rows_per_blk, re = min(R, rb + rows_per_blk);
-  const int rows_per_wave = ((rows_per_blk + 7) / 8) * 2;  // even
+  const int rows_per_wave = ((rows_per_blk + 2 * TN_WAVES - 1) / (2 * TN_WAVES)) * 2;  // even
   const int r0 = rb + wave * rows_per_wave, r1 = min(re, r0 + rows_per_wave);
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -57,36 +61,52 @@ __global__ __launch_bounds__(256) void tn_small_kernel(const float* __restrict__
       }
     }
   }
-  // ---- sum the four waves through LDS (wave 3 stores, 2..0 add), then wave 0 writes the block's slab ----
+  // ---- tree-sum the eight waves through LDS: waves [h, 2h) park their partial in slot (wave - h), waves [0, h) add it ----
   constexpr int NW = NT * 32;
-  float* cs = red + MT * 32 * NW;
 #pragma unroll
   for (int a = 0; a < MT; ++a) asum[a] += __shfl_xor(asum[a], 32, 64);
-  for (int w = 3; w >= 0; --w) {
-    if (wave == w) {
+#pragma unroll
+  for (int h = TN_WAVES / 2; h >= 1; h >>= 1) {
+    if (wave >= h && wave < 2 * h) {
+      float* slot = red + (wave - h) * SLOT;
 #pragma unroll
       for (int a = 0; a < MT; ++a) {
 #pragma unroll
         for (int b = 0; b < NT; ++b)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int m = a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, n = b * 32 + li;
-            float v = acc[a][b][e];
-            if (w != 3) v += red[m * NW + n];
-            red[m * NW + n] = v;
-          }
-        if (lh == 0) {
-          float v = asum[a];
-          if (w != 3) v += cs[a * 32 + li];
-          cs[a * 32 + li] = v;
-        }
+          for (int e = 0; e < 16; ++e) slot[(a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * NW + b * 32 + li] = acc[a][b][e];
+        if (lh == 0) slot[MT * 32 * NW + a * 32 + li] = asum[a];
+      }
+    }
+    __syncthreads();
+    if (wave < h) {
+      const float* slot = red + wave * SLOT;
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[a][b][e] += slot[(a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * NW + b * 32 + li];
+        asum[a] += slot[MT * 32 * NW + a * 32 + li];
       }
     }
     __syncthreads();
   }
-  float* slab = slabs + (long)blockIdx.x * (M * N + M);
-  for (int i = tid; i < M * N; i += 256) slab[i] = red[(i / N) * NW + (i % N)];
-  for (int i = tid; i < M; i += 256) slab[M * N + i] = cs[i];
+  // wave 0 holds the block's sum: write the slab straight from its registers
+  if (wave == 0) {
+    float* slab = slabs + (long)blockIdx.x * (M * N + M);
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, n = b * 32 + li;
+          if (m < M && n < N) slab[m * N + n] = acc[a][b][e];
+        }
+      if (lh == 0 && a * 32 + li < M) slab[M * N + a * 32 + li] = asum[a];
+    }
+  }
 }
 
 // dW[m*lddw + n] += sum_blk slab[blk][m*N+n] ; db[m] += sum_blk slab[blk][M*N+m]
@@ -109,18 +129,18 @@ __global__ void tn_small_reduce(const float* __restrict__ slabs, int nblk, int M
 
 extern "C" {
 
-size_t tatt_tn_small_workspace(int M, int N) { return (size_t)512 * ((size_t)M * N + M); }
+size_t tatt_tn_small_workspace(int M, int N) { return (size_t)TN_MAXBLK * ((size_t)M * N + M); }
 
 // dW[M,N] (row stride lddw) += dY[R,M]^T X[R,N];  db[M] += colsum(dY) (db may be null).  M <= 96, N <= 64.
 int tatt_tn_small(const float* dY, long lddy, const float* X, long ldx, float* dW, long lddw, float* db, int M, int N, int R,
                   float* workspace, hipStream_t st) {
   TATT_CHECK_ARG(M > 0 && N > 0 && R > 0 && M <= 96 && N <= 64 && workspace, "tatt_tn_small: need 0 < M <= 96, 0 < N <= 64 (got %d, %d)", M, N);
-  int nblk = (R + 127) / 128;
-  if (nblk > 512) nblk = 512;  // two blocks per CU: enough loads in flight to stream near the HBM rate
-  int rpb = ((R + nblk - 1) / nblk + 7) / 8 * 8;
+  int nblk = (R + 255) / 256;
+  if (nblk > TN_MAXBLK) nblk = TN_MAXBLK;  // one 8-wave block per CU: enough loads in flight to stream near the HBM rate
+  int rpb = ((R + nblk - 1) / nblk + 15) / 16 * 16;
   nblk = (R + rpb - 1) / rpb;
   const int MT = (M + 31) / 32, NT = (N + 31) / 32;
-#define TN_LAUNCH(a, b) hipLaunchKernelGGL((tn_small_kernel<a, b>), dim3(nblk), dim3(256), 0, st, dY, lddy, X, ldx, M, N, R, rpb, workspace)
+#define TN_LAUNCH(a, b) hipLaunchKernelGGL((tn_small_kernel<a, b>), dim3(nblk), dim3(TN_WAVES * 64), 0, st, dY, lddy, X, ldx, M, N, R, rpb, workspace)
   if (MT == 1 && NT == 1) TN_LAUNCH(1, 1);
   else if (MT == 1 && NT == 2) TN_LAUNCH(1, 2);
   else if (MT == 2 && NT == 1) TN_LAUNCH(2, 1);
