@@ -36,21 +36,24 @@ def conv_roofline(L, B, iters=10):
     mix = [(16, 64, 64, 64)] * 22 + [(16, 64, 64, 256), (16, 64, 256, 64)]
     stn = [(16, 32, 32, 64), (8, 16, 64, 128), (4, 8, 128, 256), (2, 4, 256, 256), (2, 2, 256, 256)]
     mix += stn + [(h, w, co, ci) for h, w, ci, co in stn]                     # forward + dgrad of the STN stages 1..5
+    from tatt_amd.engine import Engine
+    ws = torch.empty(8 << 20, device="cuda")
     calls, flops = [], 0.0
     for H, W, Cin, Cout in mix:
         x = torch.randn(B, H, W, Cin, device="cuda")
         wf = torch.randn(Cout * 9 * Cin, device="cuda") * 0.05
         b = torch.randn(Cout, device="cuda")
         y = torch.empty(B, H, W, Cout, device="cuda")
-        calls.append((x, wf, b, y, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 9 * Cin, 1, 0, Cin, 0, 0))
+        sk = Engine._conv_splitk(B * H * W, Cout, 9 * Cin)                   # the engine splits K on the small STN maps
+        calls.append((x, wf, b, y, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 9 * Cin, 1, 0, Cin, 0, 0, sk, ws))
         flops += 2.0 * B * H * W * Cout * 9 * Cin
     for c in calls:
-        L.conv_fwd(*c)
+        L.conv_fwd_splitk(*c)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
         for c in calls:
-            L.conv_fwd(*c)
+            L.conv_fwd_splitk(*c)
     e1.record()
     e1.synchronize()
     dt = e0.elapsed_time(e1) / (iters * len(calls)) * 1e-3

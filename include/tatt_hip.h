@@ -46,6 +46,9 @@ int tatt_tn_small(const float* dY, long lddy, const float* X, long ldx, float* d
  * (9x9 64->4) and model/stn_head.py:15.  Weights stay in the reference's OIHW layout; (w_sn,w_sci,w_base,
  * w_stap) describe how (cout, cin, tap) is addressed: forward (Cin*T, T, 0, 1); dgrad (T, Cin_f*T, T-1, -1). */
 int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu, hipStream_t stream);
+/* tatt_conv_fwd with the KH*KW*Cin reduction split `splitk` ways (workspace: splitk*B*H*W*Cout floats): the small feature
+ * maps of the STN head (model/stn_head.py:15, 4x8 .. 2x2 pixels, K up to 2304) have too few output tiles to fill the chip. */
+int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu, int splitk, float* workspace, hipStream_t stream);
 /* Per-step weight repack for tatt_conv_fwd (same nn.Conv2d weights as above): Wf[co][tap][ci] for the forward pass,
  * strides (T*Cin, 1, 0, Cin), and Wd[ci][tap][co] with the taps already flipped for dgrad, strides (T*Cout, 1, 0, Cout):
  * the kernel's weight-tile loads become 16-byte contiguous instead of stride-T gathers. */

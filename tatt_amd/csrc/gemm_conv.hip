@@ -668,9 +668,24 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
 // Wv(co,ci,tap) = Wt[co*w_sn + ci*w_sci + w_base + tap*w_stap]:
 //   forward with OIHW weights [Cout,Cin,KH,KW]:  w_sn=Cin*T, w_sci=T, w_base=0,   w_stap=1
 //   dgrad (X:=dY, Cin:=Cout_f, Cout:=Cin_f):     w_sn=T,     w_sci=Cin_f*T, w_base=T-1, w_stap=-1
+int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH,
+                         int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu,
+                         int splitk, float* workspace, hipStream_t st);
+
 int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH,
                   int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu,
                   hipStream_t st) {
+  return tatt_conv_fwd_splitk(X, Wt, bias, Y, B, H, W, Cin, Cout, KH, KW, ldx, ldy, w_sn, w_sci, w_base, w_stap, accumulate, relu, 1,
+                              nullptr, st);
+}
+
+// Same convolution with the K = KH*KW*Cin reduction split `splitk` ways into workspace slabs [splitk][B*H*W][Cout] that a
+// second kernel sums (+bias, +Y, relu): for the small feature maps of the STN head (a handful of output tiles, K up to
+// 2304) one workgroup per tile would walk 72 K-tiles in sequence while 250 CUs idle.
+int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH,
+                         int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu,
+                         int splitk, float* workspace, hipStream_t st) {
+  TATT_CHECK_ARG(splitk >= 1 && (splitk == 1 || workspace), "tatt_conv_fwd_splitk: split-K needs a workspace");
   TATT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "tatt_conv_fwd: bad dims");
   TATT_CHECK_ARG(Cin % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)X) & 15) == 0, "tatt_conv_fwd: Cin/ldx must be multiples of 4, X 16B aligned");
   TATT_CHECK_ARG((KH & 1) && (KW & 1), "tatt_conv_fwd: odd kernels only");
@@ -680,13 +695,25 @@ int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, 
   a.A = X; a.B = Wt; a.C = Y; a.bias = bias;
   a.M = B * H * W; a.N = Cout; a.K = KH * KW * Cin;
   a.ldc = ldy;
-  a.splitk = 1;
-  a.kchunk = cdiv(a.K, BK) * BK;
+  a.splitk = splitk;
+  a.kchunk = cdiv(cdiv(a.K, splitk), BK) * BK;
   a.accumulate = accumulate; a.relu = relu;
   a.g = ConvGeom{H, W, Cin, KH, KW, KH / 2, KW / 2, (int)ldx};
   a.w_sn = w_sn; a.w_sci = w_sci; a.w_base = w_base; a.w_stap = w_stap;
-  if (w_sci == 1 && (w_sn | w_stap | w_base) % 4 == 0 && (((uintptr_t)Wt) & 15) == 0) return launch<OP_IM2COL, OP_CONVW_P>(a, 1, st);
-  return launch<OP_IM2COL, OP_CONVW>(a, 1, st);
+  if (splitk > 1) {
+    a.C = workspace;
+    a.ldc = Cout;
+    a.sCz = (long)a.M * Cout;
+  }
+  int rc;
+  if (w_sci == 1 && (w_sn | w_stap | w_base) % 4 == 0 && (((uintptr_t)Wt) & 15) == 0) rc = launch<OP_IM2COL, OP_CONVW_P>(a, 1, st);
+  else rc = launch<OP_IM2COL, OP_CONVW>(a, 1, st);
+  if (rc || splitk == 1) return rc;
+  const long tot = (long)a.M * Cout;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256), 1), dim3(256), 0, st, workspace, tot, splitk, Y, bias, a.M, Cout, ldy,
+                     accumulate, relu, 0, 0, 0, 0L);
+  TATT_LAUNCH_CHECK("conv_splitk_reduce");
+  return TATT_OK;
 }
 
 // Workspace floats of tatt_conv_skinny_fwd: planar Z [T*Cout][B*H*W] + repacked weights [T*Cout][Cin].

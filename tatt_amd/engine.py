@@ -89,13 +89,15 @@ class Engine:
             s //= 2
         return max(1, s)
 
-    def linear(self, x, W, b, out, R, N, K, ldx=None, ldw=None, ldc=None, acc=0, relu=0):
-        """out[R,N] (+)= x[R,K] @ W[N,K]^T + b"""
-        self.L.gemm(x, W, out, b, R, N, K, ldx or K, 1, ldw or K, 1, ldc or N, 1, 0, 0, 0, acc, relu, 1, None)
+    def linear(self, x, W, b, out, R, N, K, ldx=None, ldw=None, ldc=None, acc=0, relu=0, splitk=1):
+        """out[R,N] (+)= x[R,K] @ W[N,K]^T + b   (splitk > 1 for the few-row, long-K products of the RPE)"""
+        self.L.gemm(x, W, out, b, R, N, K, ldx or K, 1, ldw or K, 1, ldc or N, 1, 0, 0, 0, acc, relu, splitk,
+                    self.ws if splitk > 1 else None)
 
-    def linear_dx(self, dy, W, dx, R, N, K, lddy=None, ldw=None, lddx=None, acc=0):
+    def linear_dx(self, dy, W, dx, R, N, K, lddy=None, ldw=None, lddx=None, acc=0, splitk=1):
         """dx[R,K] (+)= dy[R,N] @ W[N,K]"""
-        self.L.gemm(dy, W, dx, None, R, K, N, lddy or N, 1, 1, ldw or K, lddx or K, 1, 0, 0, 0, acc, 0, 1, None)
+        self.L.gemm(dy, W, dx, None, R, K, N, lddy or N, 1, 1, ldw or K, lddx or K, 1, 0, 0, 0, acc, 0, splitk,
+                    self.ws if splitk > 1 else None)
 
     def linear_dw(self, dy, x, dW, R, N, K, lddy=None, ldx=None, lddw=None):
         """dW[N,K] += dy[R,N]^T @ x[R,K]  (always accumulates into the gradient buffer)"""
@@ -130,20 +132,31 @@ class Engine:
             self.wpack[key] = pk
         return pk
 
+    @staticmethod
+    def _conv_splitk(M, N, K):
+        """Split the conv's K loop when it has too few output tiles to fill 256 CUs (the STN head's small maps)."""
+        tiles = -(-M // 128) * -(-N // 64)
+        if tiles >= 128 or K < 256:
+            return 1
+        sk = min(K // 64, -(-384 // tiles))
+        while sk > 1 and M * N * sk > WS_FLOATS:
+            sk //= 2
+        return max(1, sk)
+
     def conv(self, x, W, b, out, B, H, Wd, Cin, Cout, k, acc=0, relu=0):
         T = k * k
         if Cout in (4, 8, 16) and not relu:
             return self._skinny(x, W, b, out, B, H, Wd, Cin, Cout, k, (Cin * T, T, 0, 1), acc)
-        self.L.conv_fwd(x, self._packed(W, Cout, Cin, k)[0], b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout,
-                        T * Cin, 1, 0, Cin, acc, relu)
+        self.L.conv_fwd_splitk(x, self._packed(W, Cout, Cin, k)[0], b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout,
+                               T * Cin, 1, 0, Cin, acc, relu, self._conv_splitk(B * H * Wd, Cout, T * Cin), self.ws)
 
     def conv_dgrad(self, dy, W, dx, B, H, Wd, Cin, Cout, k, acc=0):
         """dx[B,H,W,Cin] (+)= conv^T(dy[B,H,W,Cout]);  W is the forward OIHW weight [Cout,Cin,k,k]."""
         T = k * k
         if Cin in (4, 8, 16):
             return self._skinny(dy, W, None, dx, B, H, Wd, Cout, Cin, k, (T, Cin * T, T - 1, -1), acc)
-        self.L.conv_fwd(dy, self._packed(W, Cout, Cin, k)[1], None, dx, B, H, Wd, Cout, Cin, k, k, Cout, Cin,
-                        T * Cout, 1, 0, Cout, acc, 0)
+        self.L.conv_fwd_splitk(dy, self._packed(W, Cout, Cin, k)[1], None, dx, B, H, Wd, Cout, Cin, k, k, Cout, Cin,
+                               T * Cout, 1, 0, Cout, acc, 0, self._conv_splitk(B * H * Wd, Cin, T * Cout), self.ws)
 
     def conv_wgrad(self, x, dy, dW, db, B, H, Wd, Cin, Cout, k):
         T = k * k
@@ -382,8 +395,8 @@ class Engine:
         xg = self.new(64, 1024)
         L.rpe_gather_x(P[ig + "init_factor.weight"], xg)
         gi = self.new(2, 64, 1536)
-        self.linear(xg, P[g + "weight_ih_l0"], P[g + "bias_ih_l0"], gi[0], 64, 1536, 1024)
-        self.linear(xg, P[g + "weight_ih_l0_reverse"], P[g + "bias_ih_l0_reverse"], gi[1], 64, 1536, 1024)
+        self.linear(xg, P[g + "weight_ih_l0"], P[g + "bias_ih_l0"], gi[0], 64, 1536, 1024, splitk=8)
+        self.linear(xg, P[g + "weight_ih_l0_reverse"], P[g + "bias_ih_l0_reverse"], gi[1], 64, 1536, 1024, splitk=8)
         hstep = self.zeros(2, B + 1, 64, 512)
         gh_all = self.new(2, B, 64, 1536)
         qp = self.new(R0, 64)
@@ -577,7 +590,7 @@ class Engine:
             self.colsum(dgh_all[dd], 64 * B, 1536, G[g + "bias_hh_l0" + sfx])
             self.linear_dw(dgi_sum[dd], xg, G[g + "weight_ih_l0" + sfx], 64, 1536, 1024)
             self.colsum(dgi_sum[dd], 64, 1536, G[g + "bias_ih_l0" + sfx])
-            self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd)
+            self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd, splitk=8)
         L.rpe_scatter_dx(dxg, G[ig + "init_factor.weight"], 1)
         on_stage("infogen")
 

@@ -110,6 +110,14 @@ def test_train_fwd_bwd_vs_oracle_with_stages(p):
     G = {n: torch.zeros_like(q) for n, q in m.named_parameters()}
     m.engine().backward(ctx, dsr, G)
     (R.image_loss(sr_o, hr).mean() * 100).backward()
+    # The same oracle in fp32 measures how far fp32 arithmetic itself lands from the fp64 statement on THIS input: a
+    # ReLU / max-pool / bilinear-cell decision of the STN head that sits on a knife edge flips for every fp32
+    # implementation alike (seen at B=4: GPU and fp32 CPU both 9.4e-3 from fp64 on stn_convnet.2, 1e-7 from each other
+    # stage by stage, tools/debug_grads.py).  The kernels are held to 3e-3, or to the fp32 oracle's own distance.
+    P32 = {k: (v.detach().float().requires_grad_(True) if v.is_floating_point() and not is_buffer(k) else
+               (v.float() if v.is_floating_point() else v.clone())) for k, v in leafify(state).items()}
+    sr32 = R.tsrn_forward(P32, lr.float(), tp.float(), training=True, drop=R.HashDropout(p, seed) if p > 0 else None)
+    (R.image_loss(sr32, hr.float()).mean() * 100).backward()
     tot = torch.sqrt(sum((P[n].grad.double() ** 2).sum() for n in G if P[n].grad is not None)).item()
     bad = []
     for n in G:
@@ -119,9 +127,10 @@ def test_train_fwd_bwd_vs_oracle_with_stages(p):
             assert float(got.abs().max()) == 0.0, n
             continue
         err = (got.double() - ref.double()).norm().item()
-        if err > 3e-3 * ref.double().norm().item() + 1e-6 * tot:     # train mode at B=4: condition number ~1e3, see above
-            bad.append((n, err, ref.norm().item()))
-    assert not bad, f"gradient mismatches vs oracle: {bad[:8]}"
+        err32 = (P32[n].grad.double() - ref.double()).norm().item()
+        if err > max(3e-3 * ref.double().norm().item(), 1.5 * err32) + 1e-6 * tot:   # train mode at B=4: condition number ~1e3
+            bad.append((n, err, err32, ref.norm().item()))
+    assert not bad, f"gradient mismatches vs oracle (name, err, fp32-oracle err, |ref|): {bad[:8]}"
 
 
 def test_eval_mode_backward_vs_oracle_fp64():

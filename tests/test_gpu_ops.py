@@ -103,6 +103,10 @@ def test_conv_fwd_dgrad_wgrad(B, H, W, Cin, Cout, k):
     L().conv_fwd(xn, wf, cu(b.detach()), out2, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, 0, 0)
     L().conv_fwd(dyn, wd, None, dx2, B, H, W, Cout, Cin, k, k, Cout, Cin, T * Cout, 1, 0, Cout, 0, 0)
     assert torch.equal(out2, out) and torch.equal(dx2, dx)
+    # split-K variant (small feature maps of the STN head), with relu and accumulate in the reduce kernel
+    out3 = cu(torch.ones(B, H, W, Cout))
+    L().conv_fwd_splitk(xn, wf, cu(b.detach()), out3, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, 1, 1, 3, ws())
+    close(out3.permute(0, 3, 1, 2), torch.relu(y + 1), what="fwd splitk+acc+relu")
     for sk in (1, 4):
         dW = torch.zeros(Cout, Cin, k, k, device="cuda")
         L().conv_wgrad(xn, dyn, dW, B, H, W, Cin, Cout, k, k, Cin, Cout, sk, ws(), 1)
