@@ -48,6 +48,7 @@ class Engine:
         self.debug = None         # set to a dict to stash intermediate gradients (tools/debug_grads.py)
         self.seed_dev = None      # optional uint32 device tensor added to the dropout seed (graph-captured training)
         self.wpack = {}
+        self._side = None         # side stream of the RPE recurrence (see forward)
 
     # ---- parameters --------------------------------------------------------------------------------
     def param_list(self):
@@ -74,6 +75,11 @@ class Engine:
         if self.ws is None or self.dev != dev:
             self.dev = dev
             self.ws = torch.empty(WS_FLOATS, device=dev, dtype=torch.float32)
+
+    def side_stream(self):
+        if self._side is None or self._side.device != self.dev:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     def new(self, *shape):
         return torch.empty(shape, device=self.dev, dtype=torch.float32)
@@ -332,6 +338,29 @@ class Engine:
         use_stn = bool(m.stn and training)
         ctx["x"] = x
 
+        # ---- recurrent positional encoding (model/transformer_v2.py:215-221): GRU over the batch axis, identical input at
+        # every step.  It depends on weights only and is a chain of B dependent, latency-bound launches, so it is forked
+        # onto a side stream here and joined where the decoder first needs query_pos; the STN head, block1 and the encoder
+        # run beside it (inside a captured hipGraph this becomes a parallel branch).
+        ig, tr = "infoGen.", "infoGen.transformer."
+        g = tr + "gru_encoding."
+        xg = self.new(64, 1024)
+        L.rpe_gather_x(P[ig + "init_factor.weight"], xg)
+        gi = self.new(2, 64, 1536)
+        self.linear(xg, P[g + "weight_ih_l0"], P[g + "bias_ih_l0"], gi[0], 64, 1536, 1024, splitk=8)
+        self.linear(xg, P[g + "weight_ih_l0_reverse"], P[g + "bias_ih_l0_reverse"], gi[1], 64, 1536, 1024, splitk=8)
+        hstep = self.zeros(2, B + 1, 64, 512)
+        gh_all = self.new(2, B, 64, 1536)
+        qp = self.new(R0, 64)
+        whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
+        dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
+        main, side = torch.cuda.current_stream(), self.side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for s in range(B):  # one fused launch per step: h_s W_hh^T, gates, h_{s+1}, query_pos (tatt_rpe_step_fwd)
+                L.rpe_step_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], hstep[0, s + 1],
+                               gh_all[0, s], qp, s, B, dsg, dsh)
+
         # ---- STN head + TPS rectification (model/tsrn.py:655-657) ------------------------------------------
         if use_stn:
             xn = self.new(R0, 4)
@@ -380,7 +409,6 @@ class Engine:
         ctx["c1"], ctx["b1"] = c1, b1
 
         # ---- TP interpreter (model/tsrn.py:194-226, model/transformer_v2.py:198-244) -----------------------------------
-        ig, tr = "infoGen.", "infoGen.transformer."
         Rt = B * 26
         tpr = self.new(Rt, K)
         L.tp_rows(text_emb, text_emb.stride(0), text_emb.stride(1), text_emb.stride(3), tpr, B, K, 26)
@@ -390,21 +418,6 @@ class Engine:
         L.prelu_fwd(t0, P[ig + "activation.weight"], t, Rt * 64)
         pos = self.new(Rt, 64)
         L.pe_dropout(P[ig + "pe.pe"], pos, B, 26, *cfg("pe"))
-        # recurrent positional encoding: GRU over the batch axis, identical input at every step
-        g = tr + "gru_encoding."
-        xg = self.new(64, 1024)
-        L.rpe_gather_x(P[ig + "init_factor.weight"], xg)
-        gi = self.new(2, 64, 1536)
-        self.linear(xg, P[g + "weight_ih_l0"], P[g + "bias_ih_l0"], gi[0], 64, 1536, 1024, splitk=8)
-        self.linear(xg, P[g + "weight_ih_l0_reverse"], P[g + "bias_ih_l0_reverse"], gi[1], 64, 1536, 1024, splitk=8)
-        hstep = self.zeros(2, B + 1, 64, 512)
-        gh_all = self.new(2, B, 64, 1536)
-        qp = self.new(R0, 64)
-        whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
-        dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
-        for s in range(B):      # one fused launch per step: h_s W_hh^T, gates, h_{s+1}, query_pos (tatt_rpe_step_fwd)
-            L.rpe_step_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], hstep[0, s + 1],
-                           gh_all[0, s], qp, s, B, dsg, dsh)
         # encoder layer (input doubled, model/transformer_v2.py:273)
         e = tr + "encoder.layers.0."
         src2, qk = self.new(Rt, 64), self.new(Rt, 64)
@@ -417,6 +430,7 @@ class Engine:
         kin = self.new(Rt, 64)
         L.axpby(mem, 1.0, pos, 1.0, kin, Rt * 64, 0)
         # decoder layers (cross attention only, model/transformer_v2.py:805-832)
+        main.wait_stream(side)                                                # join the RPE chain: query_pos is needed now
         tgt = b1
         dec = []
         tp_map = self.new(R0, 64)
@@ -476,7 +490,7 @@ class Engine:
     # ================================================================================================================
     def backward(self, ctx, dsr, G, on_stage=None):
         """Accumulates parameter gradients of one forward call into G (dict name -> fp32 tensor).
-        on_stage(name) is called when a gradient bucket is complete ("tail", "srbs", "infogen", "head"):
+        on_stage(name) is called when a gradient bucket is complete ("tail", "srbs", "head", "infogen" -- the RPE chain finishes last):
         the data-parallel trainer starts that bucket's all-reduce there, overlapping the rest of the pass."""
         on_stage = on_stage or (lambda name: None)
         L, m, P = self.L, self.m, self.P
@@ -556,6 +570,35 @@ class Engine:
             dnext = dtgt
         L.axpby(dnext, 1.0, None, 0.0, db1, R0 * 64, 1)
         L.axpby(dkin, 1.0, None, 0.0, dmem, Rt * 64, 1)                     # kin = mem + pos
+        # recurrent positional encoding, BPTT over the batch axis: dqp is complete here.  The chain of B latency-bound
+        # launches runs on the side stream beside the encoder / block1 / STN backward; its weight-gradient GEMMs (which
+        # need the shared workspace) follow after the join at the end of the pass.
+        g = tr + "gru_encoding."
+        whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
+        dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
+        carry = self.zeros(2, 64, 512)
+        dgi_sum = self.zeros(2, 64, 1536)
+        dgh_all = self.new(2, B, 64, 1536)
+        whhT = self.new(2, 512, 1536)
+        main, side = torch.cuda.current_stream(), self.side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            L.rpe_whh_transpose(whh_f, whh_b, whhT)
+            for s in reversed(range(B)):
+                L.rpe_step_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
+                               dgh_all[0, s + 1] if s + 1 < B else None, dgh_all[0, s], dgi_sum, whhT, s, B, dsg, dsh)
+
+        def rpe_finish():
+            main.wait_stream(side)
+            dxg = self.new(64, 1024)
+            for dd, sfx in enumerate(["", "_reverse"]):
+                self.linear_dw(dgh_all[dd], hstep[dd], G[g + "weight_hh_l0" + sfx], 64 * B, 1536, 512)
+                self.colsum(dgh_all[dd], 64 * B, 1536, G[g + "bias_hh_l0" + sfx])
+                self.linear_dw(dgi_sum[dd], xg, G[g + "weight_ih_l0" + sfx], 64, 1536, 1024)
+                self.colsum(dgi_sum[dd], 64, 1536, G[g + "bias_ih_l0" + sfx])
+                self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd, splitk=8)
+            L.rpe_scatter_dx(dxg, G[ig + "init_factor.weight"], 1)
+            on_stage("infogen")
         # encoder
         e = tr + "encoder.layers.0."
         ds1 = self.new(Rt, 64)
@@ -572,27 +615,6 @@ class Engine:
         dt0 = self.new(Rt, 64)
         L.prelu_bwd(t0, P[ig + "activation.weight"], dt, dt0, G[ig + "activation.weight"], 1, Rt * 64, self.ws)
         self.linear_dwb(dt0, tpr, G[ig + "fc_in.weight"], G[ig + "fc_in.bias"], Rt, 64, K)
-        # recurrent positional encoding, BPTT over the batch axis
-        g = tr + "gru_encoding."
-        whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
-        dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
-        carry = self.zeros(2, 64, 512)
-        dgi_sum = self.zeros(2, 64, 1536)
-        dgh_all = self.new(2, B, 64, 1536)
-        whhT = self.new(2, 512, 1536)
-        L.rpe_whh_transpose(whh_f, whh_b, whhT)
-        for s in reversed(range(B)):
-            L.rpe_step_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
-                           dgh_all[0, s + 1] if s + 1 < B else None, dgh_all[0, s], dgi_sum, whhT, s, B, dsg, dsh)
-        dxg = self.new(64, 1024)
-        for dd, sfx in enumerate(["", "_reverse"]):
-            self.linear_dw(dgh_all[dd], hstep[dd], G[g + "weight_hh_l0" + sfx], 64 * B, 1536, 512)
-            self.colsum(dgh_all[dd], 64 * B, 1536, G[g + "bias_hh_l0" + sfx])
-            self.linear_dw(dgi_sum[dd], xg, G[g + "weight_ih_l0" + sfx], 64, 1536, 1024)
-            self.colsum(dgi_sum[dd], 64, 1536, G[g + "bias_ih_l0" + sfx])
-            self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd, splitk=8)
-        L.rpe_scatter_dx(dxg, G[ig + "init_factor.weight"], 1)
-        on_stage("infogen")
 
         # ---- block1 ------------------------------------------------------------------------------------------------
         dc1 = self.new(R0, 64)
@@ -601,6 +623,7 @@ class Engine:
         self.conv_wgrad(xs, dc1, G["block1.0.weight"], G["block1.0.bias"], B, H, W, 4, 64, 9)
         if not ctx["use_stn"]:
             on_stage("head")
+            rpe_finish()
             return
         # ---- TPS + STN head ----------------------------------------------------------------------------------------
         stn_saved, f, l1, stat1, feat01, ctrl, Tm = ctx["stn"]
@@ -637,6 +660,7 @@ class Engine:
                 dh = self.new(Rr, cin)
                 self.conv_dgrad(dc, P[pre + "0.weight"], dh, B, hh, ww, cin, cout, 3)
         on_stage("head")
+        rpe_finish()
 
 
 # parameters that never receive a gradient in the reference: autograd must see None for them
