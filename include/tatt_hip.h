@@ -122,6 +122,16 @@ int tatt_tps_sample_bwd(const float* x, const float* ctrl, const float* T, const
 int tatt_rotate_fwd(const float* x, const float* arc, float* y, int B, int C, int H, int W, hipStream_t stream);
 int tatt_rotate_bwd(const float* arc, const float* dy, float* dx, int B, int C, int H, int W, hipStream_t stream);
 
+/* ---- TRI_SSIM, the TSC loss term (utils/ssim_psnr.py:99-128, :229-254; called at interfaces/super_resolution_eng.py:261),
+ * and the evaluation metrics SSIM (utils/ssim_psnr.py:76-96, :200-225, channels 0..Cuse-1) and calculate_psnr (:9-15).
+ * NCHW fp32, H*W <= 4096; out[0] is a device scalar; workspace: tatt_ssim_workspace(B, C) floats.  The backward adds
+ * dmean * d(mean)/d(x1), d(x2) (x3 = the HR image takes no gradient). */
+size_t tatt_ssim_workspace(int B, int C);
+int tatt_tri_ssim_fwd(const float* x1, const float* x2, const float* x3, float* out, int B, int C, int H, int W, float* workspace, hipStream_t stream);
+int tatt_tri_ssim_bwd(const float* x1, const float* x2, const float* x3, float dmean, float* dx1, float* dx2, int accumulate, int B, int C, int H, int W, hipStream_t stream);
+int tatt_ssim_fwd(const float* x1, const float* x2, float* out, int B, int Ctot, int Cuse, int H, int W, float* workspace, hipStream_t stream);
+int tatt_psnr(const float* x1, const float* x2, float* out, int B, int Ctot, int Cuse, int H, int W, float* workspace, hipStream_t stream);
+
 /* ---- ImageLoss = MSE + gradient-prior L1 (loss/image_loss.py:19-32, :40-56), NCHW ------------------------- */
 int tatt_image_loss_fwd(const float* sr, const float* hr, float* per, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);
 int tatt_image_loss_bwd(const float* sr, const float* hr, const float* dper, float uniform, float* dsr, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);

@@ -426,6 +426,7 @@ def gaussian_window(size=11, sigma=1.5) -> Tensor:
 
 def _blur(x: Tensor, win: Tensor) -> Tensor:
     C = x.shape[1]
+    win = win.to(x.dtype)           # the fp32 window values, whatever precision the referee run uses
     return F.conv2d(x, win.expand(C, 1, *win.shape).contiguous(), padding=win.shape[0] // 2, groups=C)
 
 

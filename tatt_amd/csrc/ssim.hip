@@ -1,0 +1,255 @@
+// Structural-similarity kernels: TRI_SSIM (the TSC loss of the reference, utils/ssim_psnr.py:99-128, :229-254) forward and
+// backward, and the two-image SSIM / PSNR evaluation metrics (utils/ssim_psnr.py:9-15, :76-96).
+// Layout NCHW fp32, one workgroup per (image, channel) plane; the three planes (and, in the backward pass, the four
+// per-pixel derivative fields) live in LDS, every thread walks the 11x11 Gaussian window directly (zero padding, like
+// F.conv2d(padding=5, groups=C)).  A plane is 32x128 = 16 KB, so the pass is a few hundred MFLOP of VALU work per step:
+// no tiling tricks are needed, the point is to keep the nine blurred maps out of HBM.
+#include "common.h"
+
+namespace {
+
+constexpr int WIN = 11, HALF = 5, MAXHW = 4096;
+constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+
+struct Gauss {
+  float g[WIN];
+};
+
+// gaussian(11, 1.5) as the reference builds it: float32 values of exp(), float32 sum, float32 division; the 2-D window is
+// the float32 outer product g[i]*g[j].
+Gauss make_gauss() {
+  Gauss G;
+  float sum = 0.f;
+  for (int i = 0; i < WIN; ++i) {
+    G.g[i] = (float)exp(-(double)((i - HALF) * (i - HALF)) / (2.0 * 1.5 * 1.5));
+    sum += G.g[i];
+  }
+  for (int i = 0; i < WIN; ++i) G.g[i] /= sum;
+  return G;
+}
+
+struct Blur9 {
+  float m1, m2, m3, e11, e22, e33, e12, e23, e31;
+};
+
+__device__ __forceinline__ Blur9 blur9(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                       const Gauss& G, int py, int px, int H, int W) {
+  Blur9 r = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int dy = 0; dy < WIN; ++dy) {
+    const int y = py + dy - HALF;
+    if (y < 0 || y >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < WIN; ++dx) {
+      const int x = px + dx - HALF;
+      if (x < 0 || x >= W) continue;
+      const float w = G.g[dy] * G.g[dx];
+      const float va = a[y * W + x], vb = b[y * W + x], vc = c[y * W + x];
+      r.m1 += w * va;
+      r.m2 += w * vb;
+      r.m3 += w * vc;
+      r.e11 += w * (va * va);
+      r.e22 += w * (vb * vb);
+      r.e33 += w * (vc * vc);
+      r.e12 += w * (va * vb);
+      r.e23 += w * (vb * vc);
+      r.e31 += w * (vc * va);
+    }
+  }
+  return r;
+}
+
+struct Tri {
+  float A, Bq, C, D, S;
+};
+__device__ __forceinline__ Tri tri_terms(const Blur9& r) {
+  Tri t;
+  t.A = r.m1 * r.m2 + r.m2 * r.m3 + r.m3 * r.m1 + C1;
+  t.Bq = (r.e12 - r.m1 * r.m2) + (r.e23 - r.m2 * r.m3) + (r.e31 - r.m3 * r.m1) + C2;
+  t.C = r.m1 * r.m1 + r.m2 * r.m2 + r.m3 * r.m3 + C1;
+  t.D = (r.e11 - r.m1 * r.m1) + (r.e22 - r.m2 * r.m2) + (r.e33 - r.m3 * r.m3) + C2;
+  t.S = (t.A * t.Bq) / (t.C * t.D);
+  return t;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// partial[plane] = sum over the plane of the tri-SSIM map
+__global__ __launch_bounds__(256) void tri_ssim_fwd_k(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                      const float* __restrict__ x3, float* __restrict__ partial, int H, int W,
+                                                      Gauss G) {
+  __shared__ float a[MAXHW], b[MAXHW], c[MAXHW];
+  __shared__ float red[4];
+  const int HW = H * W;
+  const long base = (long)blockIdx.x * HW;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    a[i] = x1[base + i];
+    b[i] = x2[base + i];
+    c[i] = x3[base + i];
+  }
+  __syncthreads();
+  float s = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 256) s += tri_terms(blur9(a, b, c, G, p / W, p % W, H, W)).S;
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// two-image SSIM map sum (utils/ssim_psnr.py:76-96): ((2 m1 m2 + C1)(2 s12 + C2)) / ((m1^2 + m2^2 + C1)(s1 + s2 + C2))
+__global__ __launch_bounds__(256) void ssim_fwd_k(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                  float* __restrict__ partial, int Ctot, int Cuse, int H, int W, Gauss G) {
+  __shared__ float a[MAXHW], b[MAXHW];
+  __shared__ float red[4];
+  const int HW = H * W;
+  const int img = blockIdx.x / Cuse, ch = blockIdx.x % Cuse;
+  const long base = ((long)img * Ctot + ch) * HW;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    a[i] = x1[base + i];
+    b[i] = x2[base + i];
+  }
+  __syncthreads();
+  float s = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const Blur9 r = blur9(a, b, b, G, p / W, p % W, H, W);
+    const float s1 = r.e11 - r.m1 * r.m1, s2 = r.e22 - r.m2 * r.m2, s12 = r.e12 - r.m1 * r.m2;
+    s += ((2.f * r.m1 * r.m2 + C1) * (2.f * s12 + C2)) / ((r.m1 * r.m1 + r.m2 * r.m2 + C1) * (s1 + s2 + C2));
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// partial[plane] = sum of (255 a - 255 b)^2 over the plane (calculate_psnr, utils/ssim_psnr.py:9-15, weighted_mask = 1)
+__global__ __launch_bounds__(256) void sqdiff255_k(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                   float* __restrict__ partial, int Ctot, int Cuse, int HW) {
+  __shared__ float red[4];
+  const int img = blockIdx.x / Cuse, ch = blockIdx.x % Cuse;
+  const long base = ((long)img * Ctot + ch) * HW;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float d = x1[base + i] * 255.f - x2[base + i] * 255.f;
+    s += d * d;
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// out[0] = f(scale * sum(partial)); mode 0: identity, mode 1: PSNR = 20 log10(255 / sqrt(mse))
+__global__ void ssim_final_k(const float* __restrict__ partial, int n, float scale, float* __restrict__ out, int mode) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+  s = wave_sum(s);
+  if (threadIdx.x != 0) return;
+  s *= scale;
+  out[0] = mode == 1 ? 20.f * log10f(255.f / sqrtf(s)) : s;
+}
+
+// dx1, dx2 (+)= scale * d(sum of the tri-SSIM map)/d(x1, x2).  With A, B, C, D as in tri_terms and S = AB/(CD):
+//   dS/dmu1 = (mu2+mu3) (B - A)/(CD) - 2 mu1 S (1/C - 1/D),  dS/dE12 = dS/dE31 = A/(CD),  dS/dE11 = -S/D   (same for image 2)
+// and every blurred quantity is a symmetric-window correlation, so
+//   dx1 = blur(dS/dmu1) + 2 x1 blur(dS/dE11) + (x2 + x3) blur(dS/dE12).
+__global__ __launch_bounds__(256) void tri_ssim_bwd_k(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                      const float* __restrict__ x3, float scale, float* __restrict__ dx1,
+                                                      float* __restrict__ dx2, int accumulate, int H, int W, Gauss G) {
+  __shared__ float a[MAXHW], b[MAXHW], c[MAXHW], f1[MAXHW], f2[MAXHW], fB[MAXHW], fD[MAXHW];
+  const int HW = H * W;
+  const long base = (long)blockIdx.x * HW;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    a[i] = x1[base + i];
+    b[i] = x2[base + i];
+    c[i] = x3[base + i];
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const Blur9 r = blur9(a, b, c, G, p / W, p % W, H, W);
+    const Tri t = tri_terms(r);
+    const float icd = 1.f / (t.C * t.D);
+    const float gA = t.Bq * icd, gB = t.A * icd, gC = -t.S / t.C, gD = -t.S / t.D;
+    f1[p] = (r.m2 + r.m3) * (gA - gB) + 2.f * r.m1 * (gC - gD);
+    f2[p] = (r.m1 + r.m3) * (gA - gB) + 2.f * r.m2 * (gC - gD);
+    fB[p] = gB;
+    fD[p] = gD;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < HW; q += 256) {
+    const int py = q / W, px = q % W;
+    float t1 = 0.f, t2 = 0.f, tB = 0.f, tD = 0.f;
+    for (int dy = 0; dy < WIN; ++dy) {
+      const int y = py + dy - HALF;
+      if (y < 0 || y >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < WIN; ++dx) {
+        const int x = px + dx - HALF;
+        if (x < 0 || x >= W) continue;
+        const float w = G.g[dy] * G.g[dx];
+        const int p = y * W + x;
+        t1 += w * f1[p];
+        t2 += w * f2[p];
+        tB += w * fB[p];
+        tD += w * fD[p];
+      }
+    }
+    const float g1 = scale * (t1 + 2.f * a[q] * tD + (b[q] + c[q]) * tB);
+    const float g2 = scale * (t2 + 2.f * b[q] * tD + (a[q] + c[q]) * tB);
+    dx1[base + q] = accumulate ? dx1[base + q] + g1 : g1;
+    dx2[base + q] = accumulate ? dx2[base + q] + g2 : g2;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t tatt_ssim_workspace(int B, int C) { return (size_t)B * C; }
+
+// out[0] = mean over [B,C,H,W] of the tri-SSIM map of (x1, x2, x3)  (TRI_SSIM.forward, size_average=True)
+int tatt_tri_ssim_fwd(const float* x1, const float* x2, const float* x3, float* out, int B, int C, int H, int W, float* workspace,
+                      hipStream_t st) {
+  TATT_CHECK_ARG(x1 && x2 && x3 && out && workspace && B > 0 && C > 0 && H > 0 && W > 0 && H * W <= MAXHW,
+                 "tatt_tri_ssim_fwd: bad arguments (H*W must be <= %d)", MAXHW);
+  const Gauss G = make_gauss();
+  hipLaunchKernelGGL(tri_ssim_fwd_k, dim3(B * C), dim3(256), 0, st, x1, x2, x3, workspace, H, W, G);
+  TATT_LAUNCH_CHECK("tri_ssim_fwd");
+  hipLaunchKernelGGL(ssim_final_k, dim3(1), dim3(64), 0, st, workspace, B * C, 1.f / ((float)B * C * H * W), out, 0);
+  TATT_LAUNCH_CHECK("tri_ssim_final");
+  return TATT_OK;
+}
+
+// dx1, dx2 (+)= dmean * d(mean tri-SSIM)/d(x1, x2)
+int tatt_tri_ssim_bwd(const float* x1, const float* x2, const float* x3, float dmean, float* dx1, float* dx2, int accumulate, int B,
+                      int C, int H, int W, hipStream_t st) {
+  TATT_CHECK_ARG(x1 && x2 && x3 && dx1 && dx2 && B > 0 && C > 0 && H * W <= MAXHW && H > 0 && W > 0,
+                 "tatt_tri_ssim_bwd: bad arguments (H*W must be <= %d)", MAXHW);
+  const Gauss G = make_gauss();
+  hipLaunchKernelGGL(tri_ssim_bwd_k, dim3(B * C), dim3(256), 0, st, x1, x2, x3, dmean / ((float)B * C * H * W), dx1, dx2, accumulate,
+                     H, W, G);
+  TATT_LAUNCH_CHECK("tri_ssim_bwd");
+  return TATT_OK;
+}
+
+// out[0] = SSIM(x1[:, :Cuse], x2[:, :Cuse]) averaged over everything (SSIM.forward, size_average=True); tensors are [B,Ctot,H,W]
+int tatt_ssim_fwd(const float* x1, const float* x2, float* out, int B, int Ctot, int Cuse, int H, int W, float* workspace,
+                  hipStream_t st) {
+  TATT_CHECK_ARG(x1 && x2 && out && workspace && B > 0 && Cuse > 0 && Cuse <= Ctot && H > 0 && W > 0 && H * W <= MAXHW,
+                 "tatt_ssim_fwd: bad arguments (H*W must be <= %d)", MAXHW);
+  const Gauss G = make_gauss();
+  hipLaunchKernelGGL(ssim_fwd_k, dim3(B * Cuse), dim3(256), 0, st, x1, x2, workspace, Ctot, Cuse, H, W, G);
+  TATT_LAUNCH_CHECK("ssim_fwd");
+  hipLaunchKernelGGL(ssim_final_k, dim3(1), dim3(64), 0, st, workspace, B * Cuse, 1.f / ((float)B * Cuse * H * W), out, 0);
+  TATT_LAUNCH_CHECK("ssim_final");
+  return TATT_OK;
+}
+
+// out[0] = 20 log10(255 / sqrt(mean((255 x1[:, :Cuse] - 255 x2[:, :Cuse])^2)))   (calculate_psnr)
+int tatt_psnr(const float* x1, const float* x2, float* out, int B, int Ctot, int Cuse, int H, int W, float* workspace, hipStream_t st) {
+  TATT_CHECK_ARG(x1 && x2 && out && workspace && B > 0 && Cuse > 0 && Cuse <= Ctot && H > 0 && W > 0, "tatt_psnr: bad arguments");
+  hipLaunchKernelGGL(sqdiff255_k, dim3(B * Cuse), dim3(256), 0, st, x1, x2, workspace, Ctot, Cuse, H * W);
+  TATT_LAUNCH_CHECK("psnr_partial");
+  hipLaunchKernelGGL(ssim_final_k, dim3(1), dim3(64), 0, st, workspace, B * Cuse, 1.f / ((float)B * Cuse * H * W), out, 1);
+  TATT_LAUNCH_CHECK("psnr_final");
+  return TATT_OK;
+}
+
+}  // extern "C"

@@ -461,3 +461,34 @@ def test_tps_rotate_loss_adam():
     L().clip_adam(pd_, cu(g2), m_, v_, n, 1e-3, 0.5, 0.999, 1e-8, 0.25, state, w)
     assert abs(state[0].item() - float(tot2)) < 1e-4 * float(tot2)
     assert float((pd_.cpu() - pr).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("B,C,H,W", [(3, 4, 32, 128), (2, 4, 16, 64), (1, 3, 9, 13)])
+def test_tri_ssim_ssim_psnr(B, C, H, W):
+    """TRI_SSIM forward/backward (the TSC loss term) and the SSIM / PSNR metrics against the oracle in fp64."""
+    base = torch.rand(B, C, H, W, generator=torch.Generator().manual_seed(1))
+    x1 = (base + 0.05 * rnd(B, C, H, W, seed=2)).clamp(0, 1)
+    x2 = (base + 0.05 * rnd(B, C, H, W, seed=3)).clamp(0, 1)
+    x3 = base
+    a, b_, c = (t.double().requires_grad_(True) for t in (x1, x2, x3))
+    ref = R.tri_ssim(a, b_, c)
+    ((1 - ref) * 10).backward()
+    w = ws(1024)
+    out = torch.empty(1, device="cuda")
+    L().tri_ssim_fwd(cu(x1), cu(x2), cu(x3), out, B, C, H, W, w)
+    assert abs(out.item() - ref.item()) < 2e-6, (out.item(), ref.item())
+    base1 = cu(rnd(B, C, H, W, seed=9) * 1e-4)                # accumulate onto something of the gradient's own magnitude
+    d1, d2 = base1.clone(), torch.empty(B, C, H, W, device="cuda")
+    L().tri_ssim_bwd(cu(x1), cu(x2), cu(x3), -10.0, d1, d2, 1, B, C, H, W)
+    L().tri_ssim_bwd(cu(x1), cu(x2), cu(x3), -10.0, d1.clone(), d2, 0, B, C, H, W)
+    # sigma = E[x^2] - mu^2 cancels in fp32: the tolerance is what the same fp32 arithmetic on the CPU achieves (x2)
+    a32, b32 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    ((1 - R.tri_ssim(a32, b32, x3)) * 10).backward()
+    tol = max(2e-4, 2 * rel_l2(a32.grad.double().numpy(), a.grad.numpy()))
+    close(d1.double() - base1.double(), a.grad, tol, "tri_ssim dx1 (+accumulate)")
+    close(d2, b_.grad, tol, "tri_ssim dx2")
+    if C >= 3:
+        L().ssim_fwd(cu(x1), cu(x3), out, B, C, 3, H, W, w)
+        assert abs(out.item() - R.ssim(x1.double(), x3.double()).item()) < 2e-6
+        L().psnr(cu(x1), cu(x3), out, B, C, 3, H, W, w)
+        assert abs(out.item() - R.psnr(x1.double(), x3.double()).item()) < 1e-4
