@@ -409,9 +409,10 @@ def rotate(img: Tensor, arc: Tensor) -> Tensor:
     theta = [[cos, sin*r, 0], [-sin/r, cos, 0]], r = H/W; affine_grid + grid_sample defaults."""
     N, C, H, W = img.shape
     r = H / float(W)
+    arc = arc.to(img.dtype)
     c, s = torch.cos(arc), torch.sin(arc)
-    xs = (2 * torch.arange(W, dtype=torch.float32) + 1) / W - 1              # align_corners=False base grid
-    ys = (2 * torch.arange(H, dtype=torch.float32) + 1) / H - 1
+    xs = (2 * torch.arange(W, dtype=img.dtype) + 1) / W - 1                  # align_corners=False base grid
+    ys = (2 * torch.arange(H, dtype=img.dtype) + 1) / H - 1
     gx = c.view(N, 1, 1) * xs.view(1, 1, W) + (s * r).view(N, 1, 1) * ys.view(1, H, 1)
     gy = (-s / r).view(N, 1, 1) * xs.view(1, 1, W) + c.view(N, 1, 1) * ys.view(1, H, 1)
     return grid_sample_bilinear(img, torch.stack([gx, gy], -1))
@@ -481,6 +482,49 @@ def clip_and_adam(params, grads, state, step: int, lr=1e-3, betas=(0.5, 0.999), 
         denom = (v.sqrt() / math.sqrt(1 - b2 ** step)).add_(eps)
         p.data.addcdiv_(m, denom, value=-lr / (1 - b1 ** step))
     return total
+
+
+def loss_stablizing(loss_set: Tensor, keep_proportion: float = 0.7) -> Tensor:
+    """TextSR.loss_stablizing interfaces/super_resolution_eng.py:38-48, quirk included: everything from the ORIGINAL
+    position `sorted_ind[int(keep*B)]` onward is zeroed (a data index used as a slice start, not a rank)."""
+    _, sorted_ind = torch.sort(loss_set)
+    start = int(sorted_ind[int(keep_proportion * loss_set.shape[0])])
+    mask = torch.ones_like(loss_set)
+    mask[start:] = 0.0
+    return loss_set * mask
+
+
+def tsc_losses(P: Params, lr_img: Tensor, hr_img: Tensor, tp: Tensor, arc: Tensor, drop: Optional[HashDropout] = None,
+               drop2: Optional[HashDropout] = None, training_stablize: bool = False, fused_rnn: bool = False):
+    """L_SR + L_TSC of the reference step, interfaces/super_resolution_eng.py:233-262:
+    loss_img = ImageLoss(sr, hr).mean()*100 + (1 - TRI_SSIM(D(F(Y)), F(D(Y)), D(X)))*10, with a second SR forward on
+    the rotated LR input (BatchNorm statistics update twice, fresh dropout masks = `drop2`)."""
+    sr = tsrn_forward(P, lr_img, tp, training=True, drop=drop, fused_rnn=fused_rnn)
+    per = image_loss(sr, hr_img)
+    if training_stablize:
+        per = loss_stablizing(per)
+    loss_img = per.mean() * 100
+    deformed_sr = rotate(sr, arc)
+    deformed_lr = rotate(lr_img, arc)
+    deformed_first_sr = tsrn_forward(P, deformed_lr, tp, training=True, drop=drop2, fused_rnn=fused_rnn)
+    deformed_hr = rotate(hr_img, arc)
+    loss_tssim = (1 - tri_ssim(deformed_sr, deformed_first_sr, deformed_hr)) * 10.0
+    return loss_img, loss_tssim, sr, deformed_first_sr
+
+
+def train_step_config3(P: Params, lr_img: Tensor, hr_img: Tensor, tp: Tensor, arc: Tensor, state: dict, step: int,
+                       drop: Optional[HashDropout] = None, drop2: Optional[HashDropout] = None,
+                       training_stablize: bool = False, fused_rnn: bool = False):
+    """BASELINE config 3 step in the arithmetic type of P: config 2 plus the TSC term."""
+    names = [k for k, v in P.items() if v.is_floating_point() and v.requires_grad]
+    for k in names:
+        P[k].grad = None
+    loss_img, loss_tssim, sr, sr2 = tsc_losses(P, lr_img, hr_img, tp, arc, drop, drop2, training_stablize, fused_rnn)
+    (loss_img + loss_tssim).backward()
+    params = [P[k] for k in names]
+    with torch.no_grad():
+        total = clip_and_adam(params, [p.grad for p in params], state, step)
+    return loss_img.detach(), loss_tssim.detach(), total, sr.detach(), sr2.detach()
 
 
 def train_step_config2(P: Params, lr_img: Tensor, hr_img: Tensor, tp: Tensor, state: dict, step: int,

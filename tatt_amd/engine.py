@@ -317,7 +317,9 @@ class Engine:
         return dres
 
     # ================================================================================================================
-    def forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True):
+    def forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True, wpack=None):
+        """wpack: the packed conv weights of an earlier forward call on the SAME weights (the TSC step runs the network
+        twice per optimiser step) — skips the repack."""
         L, m = self.L, self.m
         self.refresh()
         P = self.P
@@ -333,7 +335,7 @@ class Engine:
         cfg = lambda site: self.dropcfg(site, seed, p)
         ctx = Ctx()
         ctx["meta"] = (B, training, seed, p)
-        self.wpack = ctx["wpack"] = {}                       # weights change every step: repacked per forward call
+        self.wpack = ctx["wpack"] = {} if wpack is None else wpack   # weights change every step: repacked per forward call
         R0 = B * H * W
         use_stn = bool(m.stn and training)
         ctx["x"] = x

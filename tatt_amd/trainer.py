@@ -56,11 +56,15 @@ def allreduce_mean(t, async_op=False):
 
 class SRTrainer:
     def __init__(self, model, lr=1e-3, betas=(0.5, 0.999), eps=1e-8, max_norm=0.25, loss_weight=(1.0, 1e-4),
-                 use_graph=False, distributed=None):
+                 use_graph=False, distributed=None, tsc=False, tssim_rotation_degree=10.0, training_stablize=False):
         self.model, self.L = model, lib()
         self.lr, self.betas, self.eps, self.max_norm, self.loss_weight = lr, betas, eps, max_norm, loss_weight
         self.world = dist.get_world_size() if (distributed if distributed is not None else dist.is_initialized()) else 1
         self.eng = model.engine()
+        # TSC term of the reference step (interfaces/super_resolution_eng.py:249-262): second SR forward on the rotated LR
+        # input, three rotations, (1 - TRI_SSIM) * 10; `--training_stablize` masks the per-sample image loss (:241-242)
+        self.tsc, self.tssim_rotation_degree, self.training_stablize = tsc, tssim_rotation_degree, training_stablize
+        self.tssim = None                                     # device scalar: TRI_SSIM of the last step
         named = list(model.named_parameters())
         dev = named[0][1].device
         if dev.type != "cuda":
@@ -93,15 +97,43 @@ class SRTrainer:
         self.steps = 0
 
     # ------------------------------------------------------------------------------------------------------
-    def _fwd_bwd(self, lr_img, hr_img, tp, overlap):
+    @staticmethod
+    def loss_stablizing_mask(per, keep_proportion=0.7):
+        """0/1 mask of TextSR.loss_stablizing (interfaces/super_resolution_eng.py:38-48), quirk included: everything
+        from the ORIGINAL position sorted_ind[int(keep*B)] onward is dropped.  Device-side, no host sync."""
+        B = per.shape[0]
+        start = torch.argsort(per)[int(keep_proportion * B)]
+        return (torch.arange(B, device=per.device) < start).to(per.dtype)
+
+    def _fwd_bwd(self, lr_img, hr_img, tp, overlap, arc=None):
         L, B = self.L, lr_img.shape[0]
         self.flat_g.zero_()
         L.seed_bump(self.seed_dev)
         sr, ctx = self.eng.forward(lr_img, tp, True, 0)
+        C, H, W = sr.shape[1:]
         per = torch.empty(B, device=sr.device)
-        L.image_loss_fwd(sr, hr_img, per, B, 4, sr.shape[2], sr.shape[3], self.loss_weight[0], self.loss_weight[1])
+        L.image_loss_fwd(sr, hr_img, per, B, C, H, W, self.loss_weight[0], self.loss_weight[1])
         dsr = torch.empty_like(sr)
-        L.image_loss_bwd(sr, hr_img, None, 100.0 / B, dsr, B, 4, sr.shape[2], sr.shape[3], self.loss_weight[0], self.loss_weight[1])
+        if self.training_stablize:
+            mask = self.loss_stablizing_mask(per)
+            per = per * mask
+            L.image_loss_bwd(sr, hr_img, mask * (100.0 / B), 0.0, dsr, B, C, H, W, self.loss_weight[0], self.loss_weight[1])
+        else:
+            L.image_loss_bwd(sr, hr_img, None, 100.0 / B, dsr, B, C, H, W, self.loss_weight[0], self.loss_weight[1])
+        if self.tsc:
+            # D(F(Y)), F(D(Y)), D(X): the rotated SR output, the SR of the rotated input, the rotated HR image
+            arc = arc.to(device=sr.device, dtype=torch.float32)
+            d_sr, d_hr, d_lr = torch.empty_like(sr), torch.empty_like(hr_img), torch.empty_like(lr_img)
+            L.rotate_fwd(sr, arc, d_sr, B, C, H, W)
+            L.rotate_fwd(hr_img, arc, d_hr, B, C, H, W)
+            L.rotate_fwd(lr_img, arc, d_lr, B, lr_img.shape[1], lr_img.shape[2], lr_img.shape[3])
+            sr2, ctx2 = self.eng.forward(d_lr, tp, True, 1, wpack=ctx["wpack"])       # seed 1: its own dropout masks
+            self.tssim = torch.empty(1, device=sr.device)
+            L.tri_ssim_fwd(d_sr, sr2, d_hr, self.tssim, B, C, H, W, self.ws_ssim(B * C))
+            g_rot, g_sr2 = torch.empty_like(sr), torch.empty_like(sr)
+            L.tri_ssim_bwd(d_sr, sr2, d_hr, -10.0, g_rot, g_sr2, 0, B, C, H, W)      # loss_tssim = (1 - mean) * 10
+            L.rotate_bwd(arc, g_rot, dsr, B, C, H, W)                                # += onto the image-loss gradient
+            self.eng.backward(ctx2, g_sr2, self.G)
         works = []
 
         def on_stage(name):
@@ -112,16 +144,30 @@ class SRTrainer:
         self.eng.backward(ctx, dsr, self.G, on_stage=on_stage)
         return per, works
 
+    def ws_ssim(self, n):
+        if getattr(self, "_ws_ssim", None) is None or self._ws_ssim.numel() < n:
+            self._ws_ssim = torch.empty(n, device=self.flat_p.device)
+        return self._ws_ssim
+
+    def sample_arc(self, B):
+        """angle_batch = U(-deg, deg) per sample, in radians (interfaces/super_resolution_eng.py:254-255)."""
+        import math
+        return (torch.rand(B) * 2 - 1) * self.tssim_rotation_degree / 180.0 * math.pi
+
     def _update(self):
         self.L.clip_adam(self.flat_p, self.flat_g, self.m, self.v, self.n, self.lr, self.betas[0], self.betas[1], self.eps,
                          self.max_norm, self.state, self.ws)
 
-    def step(self, lr_img, hr_img, tp):
-        """One optimisation step; returns the per-sample ImageLoss [B] (device tensor, no host sync)."""
+    def step(self, lr_img, hr_img, tp, arc=None):
+        """One optimisation step; returns the per-sample ImageLoss [B] (device tensor, no host sync).  With tsc=True
+        `arc` [B] are the rotation angles in radians (drawn like the reference when omitted); the TRI_SSIM value of
+        the step is left in `self.tssim` (device scalar)."""
         self.model.train()
         hr_img = hr_img.contiguous().float()
+        if self.tsc:
+            arc = (self.sample_arc(lr_img.shape[0]) if arc is None else arc).to(device=lr_img.device, dtype=torch.float32)
         if not self.use_graph:
-            per, works = self._fwd_bwd(lr_img, hr_img, tp, overlap=self.world > 1)
+            per, works = self._fwd_bwd(lr_img, hr_img, tp, overlap=self.world > 1, arc=arc)
             for w in works:
                 if w is not None:
                     w.wait()
@@ -130,20 +176,20 @@ class SRTrainer:
             return per
         # hipGraph path: forward+backward (+ optimiser when single-GPU) captured once, replayed per step
         if self.graph is None:
-            self.static = [lr_img.clone().contiguous(), hr_img.clone(), tp.clone()]
+            self.static = [lr_img.clone().contiguous(), hr_img.clone(), tp.clone()] + ([arc.clone()] if self.tsc else [])
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):                       # warm-up outside capture (allocator, lazy module loads)
-                self._fwd_bwd(*self.static, overlap=False)
+                self._fwd_bwd(*self.static[:3], overlap=False, arc=self.static[3] if self.tsc else None)
             torch.cuda.current_stream().wait_stream(s)
             self.seed_dev.zero_()
             # the warm-up touched BatchNorm running stats: harmless for a benchmark, noted for training use
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.per, _ = self._fwd_bwd(*self.static, overlap=False)
+                self.per, _ = self._fwd_bwd(*self.static[:3], overlap=False, arc=self.static[3] if self.tsc else None)
                 if self.world == 1:
                     self._update()
-        for dst, src in zip(self.static, (lr_img, hr_img, tp)):
+        for dst, src in zip(self.static, (lr_img, hr_img, tp) + ((arc,) if self.tsc else ())):
             dst.copy_(src)
         self.graph.replay()
         if self.world > 1:

@@ -67,3 +67,71 @@ def test_graph_replay_equals_eager():
     assert torch.equal(l0, l1), "graph replay drew different dropout masks / losses than eager execution"
     assert torch.equal(p0, p1), "parameters after 3 steps differ between graph replay and eager launches"
     assert float((l0[0] - l0[1]).abs().max()) > 0, "losses identical across steps: dropout seed or update not advancing"
+
+
+def test_tsc_step_matches_oracle_step():
+    """Config-3 style step in fp32: L_SR + L_TSC (second SR forward on the rotated input, three rotations, TRI_SSIM),
+    against the oracle's fp64 statement of interfaces/super_resolution_eng.py:233-279."""
+    from tatt_amd.trainer import SRTrainer
+    B = 4
+    state = make_state(37, seed=6)
+    m = build(state)
+    m.dropout_p = 0.0
+    tr = SRTrainer(m, use_graph=False, tsc=True)
+    hr, lr, tp = procgen.make_inputs(B, 37, seed=7)
+    arc = torch.tensor([0.12, -0.05, 0.17, -0.15])
+    per = tr.step(lr.cuda(), hr.cuda(), tp.cuda(), arc=arc)
+    P = {k: (v.double().requires_grad_(True) if v.is_floating_point() and not is_buffer(k) else
+             (v.double() if v.is_floating_point() else v.clone())) for k, v in state.items()}
+    loss_img, loss_tssim, total, _, _ = R.train_step_config3(P, lr.double(), hr.double(), tp.double(), arc.double(), {}, 1)
+    assert abs(float(per.mean()) * 100 - float(loss_img)) < 2e-5 * float(loss_img)
+    assert abs((1 - float(tr.tssim)) * 10 - float(loss_tssim)) < 1e-4 * float(loss_tssim)
+    assert abs(float(tr.state[0]) - float(total)) < 5e-3 * float(total)          # global grad norm (train-mode conditioning)
+    sd = m.state_dict()
+    # BatchNorm statistics were updated twice (two SR forwards per step)
+    assert int(sd["block3.bn1.num_batches_tracked"]) == 2
+    for k in ["block3.bn1.running_mean", "block7.1.running_var", "stn_head.stn_convnet.4.1.running_mean"]:
+        assert rel_l2(sd[k].cpu().double().numpy(), P[k].detach().numpy()) < 1e-4, k
+    for k in ["block3.conv1.weight", "block8.0.conv.weight", "block5.gru2.gru.weight_hh_l0", "block1.0.weight"]:
+        d_gpu = (sd[k].cpu().double() - state[k].double()).numpy().ravel()
+        d_ref = (P[k].detach() - state[k].double()).numpy().ravel()
+        assert np.mean(np.sign(d_gpu) == np.sign(d_ref)) > 0.99, k
+
+
+def test_tsc_graph_step_runs_and_loss_stablizing_mask():
+    from tatt_amd.trainer import SRTrainer
+    B = 4
+    state = make_state(37, seed=8)
+    hr, lr, tp = [t.cuda() for t in procgen.make_inputs(B, 37, seed=9)]
+    m = build(state)
+    tr = SRTrainer(m, use_graph=True, tsc=True, training_stablize=True)
+    for _ in range(3):
+        per = tr.step(lr, hr, tp)
+    assert torch.isfinite(per).all() and 0.0 < float(tr.tssim) <= 1.0
+    assert int((per == 0).sum()) >= 1                                  # the stabiliser dropped at least one sample
+    for seed in range(5):
+        v = torch.rand(10, generator=torch.Generator().manual_seed(seed))
+        ref = R.loss_stablizing(v.clone())
+        got = v.cuda() * SRTrainer.loss_stablizing_mask(v.cuda())
+        assert torch.equal(got.cpu(), ref)
+
+
+def test_host_mirrors_tri_ssim_and_rotation_autograd():
+    """tatt_amd.utils.ssim_psnr.{TRI_SSIM,SSIM,calculate_psnr} and tatt_amd.model.torch_distortion behave like the
+    reference modules they mirror (utils/ssim_psnr.py, model/__init__.py:4-30), including autograd."""
+    from tatt_amd.model import torch_distortion
+    from tatt_amd.utils.ssim_psnr import SSIM, TRI_SSIM, calculate_psnr
+    g = torch.Generator().manual_seed(3)
+    a, b, c = (torch.rand(2, 4, 32, 128, generator=g) for _ in range(3))
+    arc = torch.tensor([0.1, -0.16])
+    ad, bd = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = (1 - R.tri_ssim(R.rotate(ad, arc), bd, R.rotate(c.double(), arc))) * 10
+    ref.backward()
+    ag, bg = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    out = (1 - TRI_SSIM()(torch_distortion(ag, arc), bg, torch_distortion(c.cuda(), arc))) * 10
+    out.backward()
+    assert abs(float(out) - float(ref)) < 1e-5
+    assert rel_l2(ag.grad.cpu().double().numpy(), ad.grad.numpy()) < 1e-3
+    assert rel_l2(bg.grad.cpu().double().numpy(), bd.grad.numpy()) < 1e-3
+    assert abs(float(SSIM()(a.cuda(), c.cuda())) - float(R.ssim(a.double(), c.double()))) < 2e-6
+    assert abs(float(calculate_psnr(a.cuda(), c.cuda())) - float(R.psnr(a.double(), c.double()))) < 1e-4
