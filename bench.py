@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_IMAGE_TRAIN = 7.70e9        # fwd+bwd, pixel+gradient loss, reference-as-executed
 PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 matrix peak
+CONV_TRAFFIC_BYTES = 34.8e6          # profiles/r01_conv_traffic.md
 
 
 def conv_roofline(L, B, iters=10):
@@ -61,7 +62,9 @@ def conv_roofline(L, B, iters=10):
     ach = fl / dt / 1e12
     return {"bound": "mfma", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST> (3x3 conv fwd+dgrad, per-step mix of %d launches)" % len(calls),
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": None, "launch_us": round(dt * 1e6, 2), "flop_per_launch": fl, "launches_per_step": len(calls)}
+            "traffic": CONV_TRAFFIC_BYTES, "traffic_note": "bytes per SRB-shaped launch (algorithmic 33.7e6): rocprofv3 --pmc 2*FETCH_SIZE"
+            " + WRITE_SIZE, separate passes, profiles/r01_conv_traffic.md (not re-measured by this run)",
+            "launch_us": round(dt * 1e6, 2), "flop_per_launch": fl, "launches_per_step": len(calls)}
 
 
 def cpu_baseline(state, B, K, steps=2):

@@ -127,7 +127,12 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave & 3, wn = wave >> 2;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive M tiles -
+  // which share their im2col halo rows - would land on 8 different L2s and every halo row would be fetched twice from
+  // the fabric (measured: FETCH_SIZE = 2x the input).  Give each XCD a contiguous range of M tiles instead.
+  int bx = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+  const int m0 = bx * BM, n0 = blockIdx.y * BN;
   const int zb = blockIdx.z / a.splitk, zs = blockIdx.z % a.splitk;
   const float* __restrict__ Ap = a.A + zb * a.sAb;
   const float* __restrict__ Bp = a.B + zb * a.sBb;

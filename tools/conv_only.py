@@ -1,12 +1,13 @@
-"""Runs only the SRB conv (fwd, dgrad, wgrad) a few times: target for rocprofv3 --pmc passes."""
+"""Runs only the SRB-shaped packed conv (gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST>, 3x3 64->64 on [64,16,64]) a few times:
+target for the rocprofv3 --pmc passes that measure its HBM-side traffic (profiles/r01_conv_traffic.md)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tatt_amd.lib import lib
 L = lib(); B = 64; R = B * 1024
-x, y, w, b, dw = [torch.randn(*s, device="cuda") for s in ((R, 64), (R, 64), (64, 64, 3, 3), (64,), (64, 64, 3, 3))]
-ws = torch.empty(48 << 20, device="cuda")
+x, y, w, b = [torch.randn(*s, device="cuda") for s in ((R, 64), (R, 64), (64, 64, 3, 3), (64,))]
+wf, wd = torch.empty(64 * 576, device="cuda"), torch.empty(64 * 576, device="cuda")
+L.conv_pack_w(w, wf, wd, 64, 64, 3, 3)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
-    L.conv_fwd(x, w, b, y, B, 16, 64, 64, 64, 3, 3, 64, 64, 576, 9, 0, 1, 0, 0)
-    L.conv_wgrad(x, y, dw, B, 16, 64, 64, 64, 3, 3, 64, 64, 205, ws, 1)
+    L.conv_fwd(x, wf, b, y, B, 16, 64, 64, 64, 3, 3, 64, 64, 576, 1, 0, 64, 0, 0)
 torch.cuda.synchronize()
