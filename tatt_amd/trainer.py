@@ -59,7 +59,10 @@ class SRTrainer:
                  use_graph=False, distributed=None, tsc=False, tssim_rotation_degree=10.0, training_stablize=False):
         self.model, self.L = model, lib()
         self.lr, self.betas, self.eps, self.max_norm, self.loss_weight = lr, betas, eps, max_norm, loss_weight
-        self.world = dist.get_world_size() if (distributed if distributed is not None else dist.is_initialized()) else 1
+        # data parallel whenever a process group exists (a 1-rank group takes the same broadcast / all-reduce path, which is
+        # how the RCCL plumbing is tested on a single GPU)
+        self.dp = bool(distributed if distributed is not None else dist.is_initialized())
+        self.world = dist.get_world_size() if self.dp else 1
         self.eng = model.engine()
         # TSC term of the reference step (interfaces/super_resolution_eng.py:249-262): second SR forward on the rotated LR
         # input, three rotations, (1 - TRI_SSIM) * 10; `--training_stablize` masks the per-sample image loss (:241-242)
@@ -84,7 +87,7 @@ class SRTrainer:
             p.data = self.flat_p[sl].view(p.shape)
             self.G[n] = self.flat_g[sl].view(p.shape)
             p.grad = self.G[n]
-        if self.world > 1:                                    # identical replicas: rank 0's initial weights + buffers
+        if self.dp:                                           # identical replicas: rank 0's initial weights + buffers
             dist.broadcast(self.flat_p, 0)
             for b in model.buffers():
                 dist.broadcast(b, 0)
@@ -167,7 +170,7 @@ class SRTrainer:
         if self.tsc:
             arc = (self.sample_arc(lr_img.shape[0]) if arc is None else arc).to(device=lr_img.device, dtype=torch.float32)
         if not self.use_graph:
-            per, works = self._fwd_bwd(lr_img, hr_img, tp, overlap=self.world > 1, arc=arc)
+            per, works = self._fwd_bwd(lr_img, hr_img, tp, overlap=self.dp, arc=arc)
             for w in works:
                 if w is not None:
                     w.wait()
@@ -187,12 +190,12 @@ class SRTrainer:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.per, _ = self._fwd_bwd(*self.static[:3], overlap=False, arc=self.static[3] if self.tsc else None)
-                if self.world == 1:
+                if not self.dp:
                     self._update()
         for dst, src in zip(self.static, (lr_img, hr_img, tp) + ((arc,) if self.tsc else ())):
             dst.copy_(src)
         self.graph.replay()
-        if self.world > 1:
+        if self.dp:
             works = [allreduce_mean(self.flat_g[a:b], async_op=True) for a, b in self.bucket_range]
             for w in works:
                 if w is not None:
