@@ -132,6 +132,18 @@ int tatt_tri_ssim_bwd(const float* x1, const float* x2, const float* x3, float d
 int tatt_ssim_fwd(const float* x1, const float* x2, float* out, int B, int Ctot, int Cuse, int H, int W, float* workspace, hipStream_t stream);
 int tatt_psnr(const float* x1, const float* x2, float* out, int B, int Ctot, int Cuse, int H, int W, float* workspace, hipStream_t stream);
 
+/* ---- CRNN text-prior generator, forward (model/crnn/crnn.py:45-119) -----------------------------
+ * tatt_crnn_prep = parse_crnn_data (interfaces/base.py:441-459): bicubic resize (torch defaults) of channels 0..2 + gray,
+ * NCHW in -> NHWC out with C padded to 4 (channel 0 = gray).  tatt_maxpool_gen_fwd = nn.MaxPool2d(kernel, stride, padding)
+ * (crnn.py:77-85), NHWC.  tatt_linear_f64 = the `embedding` Linear evaluated in float64 (crnn.py:31-33).
+ * tatt_lstm256_step_fwd = one time step of nn.LSTM(nIn, 256, bidirectional=True) (crnn.py:10,:19): gi [T*B][2*1024] is
+ * W_ih x + b_ih of both directions (time-major rows), h/c state [2][B][256] (hprev and hout must not alias),
+ * out [T*B][512]; step s handles time s for direction 0 and T-1-s for direction 1. */
+int tatt_crnn_prep(const float* x, float* y, int B, int Ctot, int H, int W, int OH, int OW, hipStream_t stream);
+int tatt_maxpool_gen_fwd(const float* x, float* y, int B, int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW, hipStream_t stream);
+int tatt_linear_f64(const float* x, long ldx, const float* Wt, const float* bias, float* out, long ldo, int R, int N, int K, hipStream_t stream);
+int tatt_lstm256_step_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, const float* hprev, const float* cprev, float* hout, float* cout, float* out, int s, int T, int B, hipStream_t stream);
+
 /* ---- ImageLoss = MSE + gradient-prior L1 (loss/image_loss.py:19-32, :40-56), NCHW ------------------------- */
 int tatt_image_loss_fwd(const float* sr, const float* hr, float* per, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);
 int tatt_image_loss_bwd(const float* sr, const float* hr, const float* dper, float uniform, float* dsr, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);

@@ -1,4 +1,4 @@
-from . import tsrn, transformer_v2, stn_head, tps_spatial_transformer  # noqa: F401
+from . import tsrn, transformer_v2, stn_head, tps_spatial_transformer, crnn  # noqa: F401
 
 import torch as _torch
 

@@ -87,3 +87,35 @@ def test_tps_buffers_match_module():
     sd = TSRN_TL_TRANS().state_dict()
     for k, v in R.tps_buffers().items():
         assert torch.allclose(sd["tps." + k], v, atol=1e-6), k
+
+
+@pytest.mark.parametrize("name,train", [("crnn_B2_eval", False), ("crnn_B3_train", True)])
+def test_crnn_oracle_vs_reference_golden(name, train):
+    """oracle/crnn_ref.py (parse_crnn_data, CRNN.forward with the float64 embedding) against outputs of the real reference
+    CRNN (tests/golden/make_golden_crnn.py), on HR- and LR-sized inputs, eval and train-mode BatchNorm."""
+    import copy
+    import os
+    from oracle import crnn_ref as C
+    from tests.util import rel_l2
+    GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    from oracle import procgen
+    from tatt_amd.model.crnn import CRNN
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    B = gold["hr/gray"].shape[0]
+    state0 = procgen.fill_state(CRNN().state_dict(), seed=3)
+    hr, lr, _ = procgen.make_inputs(B, 37, seed=4)
+    P = None
+    for tag, img in (("hr", hr), ("lr", lr)):
+        if P is None or not train:
+            P = copy.deepcopy(state0)
+        gray = C.parse_crnn_data(img)
+        assert np.abs(gray.numpy() - gold[tag + "/gray"]).max() < 2e-6
+        inter = {}
+        logits = C.crnn_forward(P, gray, training=train, inter=inter)
+        tol = 2e-5 if train else 2e-6                        # batch statistics: fp32 summation order differs from ATen's
+        assert rel_l2(inter["cnn"].numpy(), gold[tag + "/cnn"]) < tol
+        assert rel_l2(inter["rnn0"].numpy(), gold[tag + "/rnn0"]) < tol
+        assert rel_l2(logits.numpy(), gold[tag + "/logits"]) < tol
+    if train:                                               # the reference ran hr then lr on ONE module: stats updated twice
+        for k in ("cnn.batchnorm2.running_mean", "cnn.batchnorm6.running_var"):
+            assert rel_l2(P[k].numpy(), gold["bn/" + k]) < 1e-6
