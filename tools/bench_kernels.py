@@ -100,3 +100,10 @@ t("rpe_step_fwd (fused)", lambda: L.rpe_step_fwd(gi_, whf, whb, bhf, bhb, hst[0,
 whT, car, dga, dgs = rnd(2, 512, 1536), rnd(2, 64, 512), rnd(2, B, 64, 1536), torch.zeros(2, 64, 1536, device="cuda")
 t("rpe_step_bwd (fused)", lambda: L.rpe_step_bwd(gi_, gha[0, 3], bhf, bhb, hst[0, 3], qp_, car, dga[0, 4], dga[0, 3], dgs, whT, 3, B, dsg_, dsh_), 2 * 2 * 64 * 1536 * 512, 0)
 t("rpe_whh_transpose", lambda: L.rpe_whh_transpose(whf, whb, whT), 0, 2 * 1536 * 512 * 8)
+
+# CRNN prior generator forward (teacher), B = 64
+from tatt_amd.model.crnn import CRNN
+crnn = CRNN().cuda().eval()
+lr_img = torch.rand(B, 4, 16, 64, device="cuda")
+with torch.no_grad():
+    t("CRNN forward from LR images (B=64)", lambda: crnn.forward_from_images(lr_img), 0, 0, iters=5)
