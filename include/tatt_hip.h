@@ -142,7 +142,20 @@ int tatt_psnr(const float* x1, const float* x2, float* out, int B, int Ctot, int
 int tatt_crnn_prep(const float* x, float* y, int B, int Ctot, int H, int W, int OH, int OW, hipStream_t stream);
 int tatt_maxpool_gen_fwd(const float* x, float* y, int B, int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW, hipStream_t stream);
 int tatt_linear_f64(const float* x, long ldx, const float* Wt, const float* bias, float* out, long ldo, int R, int N, int K, hipStream_t stream);
-int tatt_lstm256_step_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, const float* hprev, const float* cprev, float* hout, float* cout, float* out, int s, int T, int B, hipStream_t stream);
+int tatt_lstm256_step_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, const float* hprev, const float* cprev, float* hout, float* cout, float* out, float* save, int s, int T, int B, hipStream_t stream);
+/* Backward pieces of the CRNN student (autograd of the modules above).  tatt_lstm256_step_bwd: BPTT step s (call with
+ * s = T-1 .. 0); save [T*B][2][5][256] is what tatt_lstm256_step_fwd stored (i, f, g, o, c), whhT [2][256][1024] = W_hh^T
+ * per direction (tatt_transpose), dout = d(out), dgates [T*B][2048] receives the pre-activation gate gradients (read back by
+ * the next call and by the caller's weight-gradient GEMMs), dc_carry [2][B][256] is scratch carried between calls.
+ * tatt_maxpool_gen_bwd: gather form of MaxPool2d's backward (first maximum wins, deterministic). */
+int tatt_lstm256_step_bwd(const float* save, const float* whhT, const float* dout, float* dgates, float* dc_carry, int s, int T, int B, hipStream_t stream);
+int tatt_transpose(const float* in, float* out, int rows, int cols, hipStream_t stream);
+int tatt_maxpool_gen_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW, hipStream_t stream);
+/* SemanticLoss (loss/semantic_loss.py:21-38: mean |gt - pred| + KLDivLoss()(log(pred + 1e-20), gt + 1e-20)) fused with the two
+ * softmaxes of the trainer (interfaces/super_resolution_eng.py:222-228,:240): zs / zt = student / teacher logits [R = T*B, K];
+ * out[0] = loss; if dzs != NULL, dzs = dloss * d loss / d zs.  workspace: tatt_semantic_loss_workspace(R) floats. */
+size_t tatt_semantic_loss_workspace(int R);
+int tatt_semantic_loss(const float* zs, const float* zt, float* out, float* dzs, float dloss, int R, int K, float* workspace, hipStream_t stream);
 
 /* ---- ImageLoss = MSE + gradient-prior L1 (loss/image_loss.py:19-32, :40-56), NCHW ------------------------- */
 int tatt_image_loss_fwd(const float* sr, const float* hr, float* per, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);

@@ -101,7 +101,7 @@ constexpr int LH = 256;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_step_fwd_k(
     const float* __restrict__ gi, const float* __restrict__ whh_f, const float* __restrict__ whh_b, const float* __restrict__ bhh_f,
     const float* __restrict__ bhh_b, const float* __restrict__ hprev, const float* __restrict__ cprev, float* __restrict__ hout,
-    float* __restrict__ cout, float* __restrict__ out, int s, int T, int B) {
+    float* __restrict__ cout, float* __restrict__ out, float* __restrict__ save, int s, int T, int B) {
   __shared__ float red[4][64][17];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, q = lane >> 4;
   const int dir = blockIdx.y, j0 = blockIdx.x * 4, rb = blockIdx.z * 64;
@@ -159,6 +159,174 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   cout[((long)dir * B + row) * LH + j] = c;
   hout[((long)dir * B + row) * LH + j] = h;
   out[((long)t * B + row) * (2 * LH) + dir * LH + j] = h;
+  if (save) {  // [T*B][2][5][256]: i, f, g, o, c of this step (for lstm_step_bwd_k)
+    float* sp = save + (((long)t * B + row) * 2 + dir) * 5 * LH + j;
+    sp[0] = ig;
+    sp[LH] = fg;
+    sp[2 * LH] = gg;
+    sp[3 * LH] = og;
+    sp[4 * LH] = c;
+  }
+}
+
+// BPTT step s (forward-order time t = s for dir 0, T-1-s for dir 1; the launches run s = T-1 .. 0).
+// Block (jb, mh, dir) owns rows mh*32..+31 and hidden units jb*16..+15:
+//   dh = dout[t] + dgates_{next}[.,1024] W_hh          (K = 1024 split over the four waves; `next` = the step launched before)
+//   dc = dc_carry + dh o (1 - tanh^2 c);  gate gradients;  dc_carry <- dc f;  dgates[t] written for the next launch / the GEMMs
+// whhT [2][256][1024] = W_hh^T; dgates [T*B][2048] (dir*1024 + gate*256 + j).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_step_bwd_k(
+    const float* __restrict__ save, const float* __restrict__ whhT, const float* __restrict__ dout, float* __restrict__ dgates,
+    float* __restrict__ dc_carry, int s, int T, int B) {
+  __shared__ float red[4][32][17];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int jb = blockIdx.x, mh = blockIdx.y, dir = blockIdx.z;
+  const int t = dir ? T - 1 - s : s;
+  const int tn = dir ? t - 1 : t + 1;  // time index of the step that ran after this one in the forward recurrence
+  const bool has_next = s + 1 < T;
+  if (has_next) {
+    const float* A = dgates + ((long)tn * B + mh * 32 + i) * (8 * LH) + dir * 4 * LH + wv * 256 + q * 4;
+    const float* Bt = whhT + ((long)dir * LH + jb * 16 + i) * (4 * LH) + wv * 256 + q * 4;
+    float4 af[2][16], bf[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      bf[e] = *reinterpret_cast<const float4*>(Bt + 16 * e);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const bool on = mh * 32 + mt * 16 + i < B;
+        af[mt][e] = on ? *reinterpret_cast<const float4*>(A + (long)mt * 16 * (8 * LH) + 16 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e].x, bf[e].x, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e].y, bf[e].y, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e].z, bf[e].z, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e].w, bf[e].w, acc[mt], 0, 0, 0);
+      }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wv][mt * 16 + 4 * q + r][i] = acc[mt][r];
+  }
+  __syncthreads();
+  const int tp = dir ? t + 1 : t - 1;  // forward-order predecessor (its c is c_prev of this step)
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int e = tid + 256 * h2, wl = e >> 4, jj = e & 15;
+    const int row = mh * 32 + wl, j = jb * 16 + jj;
+    if (row >= B) continue;
+    float dh = dout[((long)t * B + row) * (2 * LH) + dir * LH + j];
+    if (has_next) dh += (red[0][wl][jj] + red[1][wl][jj]) + (red[2][wl][jj] + red[3][wl][jj]);
+    const float* sp = save + (((long)t * B + row) * 2 + dir) * 5 * LH + j;
+    const float ig = sp[0], fg = sp[LH], gg = sp[2 * LH], og = sp[3 * LH], c = sp[4 * LH];
+    const float cprev = (s > 0) ? save[(((long)tp * B + row) * 2 + dir) * 5 * LH + 4 * LH + j] : 0.f;
+    const float tc = tanhf_(c);
+    const long ci = ((long)dir * B + row) * LH + j;
+    const float dc = (has_next ? dc_carry[ci] : 0.f) + dh * og * (1.f - tc * tc);
+    float* o = dgates + ((long)t * B + row) * (8 * LH) + dir * 4 * LH + j;
+    o[0] = dc * gg * ig * (1.f - ig);
+    o[LH] = dc * cprev * fg * (1.f - fg);
+    o[2 * LH] = dc * ig * (1.f - gg * gg);
+    o[3 * LH] = dh * tc * og * (1.f - og);
+    dc_carry[ci] = dc * fg;
+  }
+}
+
+// out[c][r] = in[r][c]
+__global__ void transpose_k(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  __shared__ float t[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) t[r][tx] = (r0 + r < rows && c0 + tx < cols) ? in[(long)(r0 + r) * cols + c0 + tx] : 0.f;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (c0 + r < cols && r0 + tx < rows) out[(long)(c0 + r) * rows + r0 + tx] = t[tx][r];
+}
+
+// MaxPool2d backward as a gather (windows overlap when stride < kernel): an input element receives dy of every window
+// whose arg-max (first maximum in (dy, dx) scan order, like ATen) it is.  Deterministic, no atomics.
+__global__ void maxpool_gen_bwd_k(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int B, int H,
+                                  int W, int C, int KH, int KW, int SH, int SW, int PH, int PW, int OH, int OW) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * H * W * C) return;
+  const int c = i % C;
+  const int xx = (i / C) % W, yy = (i / ((long)C * W)) % H, b = i / ((long)C * W * H);
+  float g = 0.f;
+  const int oy0 = max(0, (yy + PH - KH + SH) / SH), oy1 = min(OH - 1, (yy + PH) / SH);
+  const int ox0 = max(0, (xx + PW - KW + SW) / SW), ox1 = min(OW - 1, (xx + PW) / SW);
+  for (int oy = oy0; oy <= oy1; ++oy)
+    for (int ox = ox0; ox <= ox1; ++ox) {
+      float m = -INFINITY;
+      int ay = -1, ax = -1;
+      for (int a = 0; a < KH; ++a) {
+        const int y2 = oy * SH - PH + a;
+        if (y2 < 0 || y2 >= H) continue;
+        for (int d = 0; d < KW; ++d) {
+          const int x2 = ox * SW - PW + d;
+          if (x2 < 0 || x2 >= W) continue;
+          const float v = x[(((long)b * H + y2) * W + x2) * C + c];
+          if (v > m) {
+            m = v;
+            ay = y2;
+            ax = x2;
+          }
+        }
+      }
+      if (ay == yy && ax == xx) g += dy[(((long)b * OH + oy) * OW + ox) * C + c];
+    }
+  dx[i] = g;
+}
+
+// ---- SemanticLoss (loss/semantic_loss.py:21-38) fused with the two softmaxes that feed it ---------------------------------
+// pred = softmax(zs), gt = softmax(zt) over K classes; per row: sum |gt - pred| and sum (gt+1e-20)(log(gt+1e-20) - log(pred+1e-20));
+// loss = (mean |gt - pred| + mean KL) over all R*K elements.  dzs (+)= dloss * d loss / d zs through the softmax.
+__global__ void semantic_loss_k(const float* __restrict__ zs, const float* __restrict__ zt, float* __restrict__ partial,
+                                float* __restrict__ dzs, float dscale, int R, int K) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  float tot = 0.f;
+  if (r < R) {
+    const float* a = zs + (long)r * K;
+    const float* b = zt + (long)r * K;
+    float ma = -INFINITY, mb = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      ma = fmaxf(ma, a[k]);
+      mb = fmaxf(mb, b[k]);
+    }
+    float sa = 0.f, sb = 0.f;
+    for (int k = 0; k < K; ++k) {
+      sa += expf(a[k] - ma);
+      sb += expf(b[k] - mb);
+    }
+    float gdot = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float p = expf(a[k] - ma) / sa, g = expf(b[k] - mb) / sb;
+      tot += fabsf(g - p) + (g + 1e-20f) * (logf(g + 1e-20f) - logf(p + 1e-20f));
+      if (dzs) {
+        const float d = (p > g ? 1.f : (p < g ? -1.f : 0.f)) - (g + 1e-20f) / (p + 1e-20f);
+        gdot += d * p;
+      }
+    }
+    if (dzs)
+      for (int k = 0; k < K; ++k) {
+        const float p = expf(a[k] - ma) / sa, g = expf(b[k] - mb) / sb;
+        const float d = (p > g ? 1.f : (p < g ? -1.f : 0.f)) - (g + 1e-20f) / (p + 1e-20f);
+        dzs[(long)r * K + k] = dscale * p * (d - gdot);
+      }
+  }
+  __shared__ float red[4];
+  tot = wave_sum(tot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void semantic_final_k(const float* __restrict__ partial, int n, float scale, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[0] = s * scale;
 }
 
 }  // namespace
@@ -194,13 +362,54 @@ int tatt_linear_f64(const float* x, long ldx, const float* Wt, const float* bias
 }
 
 int tatt_lstm256_step_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b,
-                          const float* hprev, const float* cprev, float* hout, float* cout, float* out, int s, int T, int B,
+                          const float* hprev, const float* cprev, float* hout, float* cout, float* out, float* save, int s, int T, int B,
                           hipStream_t st) {
   TATT_CHECK_ARG(gi && whh_f && whh_b && bhh_f && bhh_b && hprev && cprev && hout && cout && out && s >= 0 && s < T && B > 0,
                  "tatt_lstm256_step_fwd: bad arguments");
   hipLaunchKernelGGL(lstm_step_fwd_k, dim3(LH / 4, 2, cdiv(B, 64)), dim3(256), 0, st, gi, whh_f, whh_b, bhh_f, bhh_b, hprev, cprev,
-                     hout, cout, out, s, T, B);
+                     hout, cout, out, save, s, T, B);
   TATT_LAUNCH_CHECK("lstm_step_fwd");
+  return TATT_OK;
+}
+
+int tatt_lstm256_step_bwd(const float* save, const float* whhT, const float* dout, float* dgates, float* dc_carry, int s, int T, int B,
+                          hipStream_t st) {
+  TATT_CHECK_ARG(save && whhT && dout && dgates && dc_carry && s >= 0 && s < T && B > 0, "tatt_lstm256_step_bwd: bad arguments");
+  hipLaunchKernelGGL(lstm_step_bwd_k, dim3(LH / 16, cdiv(B, 32), 2), dim3(256), 0, st, save, whhT, dout, dgates, dc_carry, s, T, B);
+  TATT_LAUNCH_CHECK("lstm_step_bwd");
+  return TATT_OK;
+}
+
+int tatt_transpose(const float* in, float* out, int rows, int cols, hipStream_t st) {
+  TATT_CHECK_ARG(in && out && rows > 0 && cols > 0, "tatt_transpose: bad arguments");
+  hipLaunchKernelGGL(transpose_k, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, st, in, out, rows, cols);
+  TATT_LAUNCH_CHECK("transpose");
+  return TATT_OK;
+}
+
+int tatt_maxpool_gen_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int KH, int KW, int SH, int SW, int PH,
+                         int PW, hipStream_t st) {
+  TATT_CHECK_ARG(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0 && SH > 0 && SW > 0 && PH >= 0 && PW >= 0 &&
+                     2 * PH <= KH && 2 * PW <= KW, "tatt_maxpool_gen_bwd: bad arguments");
+  const int OH = (H + 2 * PH - KH) / SH + 1, OW = (W + 2 * PW - KW) / SW + 1;
+  hipLaunchKernelGGL(maxpool_gen_bwd_k, dim3(cdiv((long)B * H * W * C, 256)), dim3(256), 0, st, x, dy, dx, B, H, W, C, KH, KW, SH, SW,
+                     PH, PW, OH, OW);
+  TATT_LAUNCH_CHECK("maxpool_gen_bwd");
+  return TATT_OK;
+}
+
+size_t tatt_semantic_loss_workspace(int R) { return (size_t)cdiv(R, 256); }
+
+// out[0] = SemanticLoss(softmax(zs), softmax(zt)); if dzs: dzs = dloss * d out / d zs (zt, the teacher, takes no gradient)
+int tatt_semantic_loss(const float* zs, const float* zt, float* out, float* dzs, float dloss, int R, int K, float* workspace,
+                       hipStream_t st) {
+  TATT_CHECK_ARG(zs && zt && out && workspace && R > 0 && K > 0, "tatt_semantic_loss: bad arguments");
+  const int nb = cdiv(R, 256);
+  const float inv = 1.f / ((float)R * K);
+  hipLaunchKernelGGL(semantic_loss_k, dim3(nb), dim3(256), 0, st, zs, zt, workspace, dzs, dloss * inv, R, K);
+  TATT_LAUNCH_CHECK("semantic_loss");
+  hipLaunchKernelGGL(semantic_final_k, dim3(1), dim3(64), 0, st, workspace, nb, inv, out);
+  TATT_LAUNCH_CHECK("semantic_final");
   return TATT_OK;
 }
 

@@ -161,7 +161,7 @@ def test_gemm_batched_splitk():
 
 
 @pytest.mark.parametrize("R_,C,act", [(2048, 64, 2), (100, 32, 1), (4, 512, 1), (20000, 256, 0), (4, 256, 1), (256, 128, 1),
-                                       (1024, 64, 1), (64, 256, 1), (16, 256, 1)])
+                                       (1024, 64, 1), (64, 256, 1), (16, 256, 1), (312, 512, 1), (600, 256, 1), (78, 512, 1)])
 def test_batchnorm_train_fwd_bwd(R_, C, act):
     x = (rnd(R_, C) * 2 + 0.5).requires_grad_(True)
     g_, b_ = (1 + 0.2 * rnd(C, seed=1)).requires_grad_(True), rnd(C, seed=2).requires_grad_(True)
