@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--K", type=int, default=37)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full", action="store_true", help="the reference's whole train() iteration: teacher + student CRNN priors, "
+                                                       "SemanticLoss, two-group Adam around the SR step (SURVEY §8f ranks 1-2)")
     ap.add_argument("--tsc", action="store_true", help="add the TSC term (second SR forward on rotated input + TRI_SSIM): "
                                                       "BASELINE config 3's step in fp32; off = config 2, the default metric")
     a = ap.parse_args()
@@ -118,8 +120,13 @@ def main():
                           text_embedding=a.K)
     state_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.cuda().train()
-    trainer = SRTrainer(model, lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, loss_weight=(1.0, 1e-4), use_graph=not a.no_graph,
-                        tsc=a.tsc)
+    kw = dict(lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, loss_weight=(1.0, 1e-4), use_graph=not a.no_graph, tsc=a.tsc)
+    if a.full:
+        from tatt_amd.model.crnn import CRNN
+        from tatt_amd.trainer import TATTTrainer
+        trainer = TATTTrainer(model, CRNN().cuda(), CRNN().cuda(), lr_tpg=1e-4, **kw)
+    else:
+        trainer = SRTrainer(model, **kw)
     hr, lr, tp = synthetic_batch(a.batch, a.K, seed=123 + rank, device="cuda")
 
     for _ in range(a.warmup):
@@ -149,7 +156,9 @@ def main():
             "metric": "train images/sec (whole node) TATT 16x64->32x128", "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE config 3 step in fp32 (config 2 + TSC: second SR forward on the rotated input, "
+            "config": {"workload": ("whole reference iteration in fp32: CRNN teacher + student priors, SR step%s, SemanticLoss, "
+                                    "two-group Adam, K=%d" % (" + TSC" if a.tsc else "", a.K)) if a.full else
+                                   ("BASELINE config 3 step in fp32 (config 2 + TSC: second SR forward on the rotated input, "
                                     "TRI_SSIM x10), K=%d" % a.K) if a.tsc else
                                    "BASELINE config 2: TSRN_TL_TRANS(STN, K=%d) single training step fp32, pixel+gradient loss, "
                                    "clip 0.25 + Adam, frozen text prior" % a.K,
@@ -159,7 +168,7 @@ def main():
             "model_frac_of_f32_mfma_peak": round(value * FLOP_PER_IMAGE_TRAIN * (2 if a.tsc else 1) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
         }
         out["roofline"] = conv_roofline(lib(), a.batch)
-        if world == 1 and not a.no_cpu_baseline and not a.tsc:
+        if world == 1 and not a.no_cpu_baseline and not a.tsc and not a.full:
             out["cpu_baseline"] = cpu_baseline(state_cpu, a.batch, a.K)
         print(json.dumps(out), flush=True)
     if world > 1:

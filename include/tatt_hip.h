@@ -154,6 +154,8 @@ int tatt_maxpool_gen_bwd(const float* x, const float* dy, float* dx, int B, int 
 /* SemanticLoss (loss/semantic_loss.py:21-38: mean |gt - pred| + KLDivLoss()(log(pred + 1e-20), gt + 1e-20)) fused with the two
  * softmaxes of the trainer (interfaces/super_resolution_eng.py:222-228,:240): zs / zt = student / teacher logits [R = T*B, K];
  * out[0] = loss; if dzs != NULL, dzs = dloss * d loss / d zs.  workspace: tatt_semantic_loss_workspace(R) floats. */
+int tatt_semantic_loss_probs(const float* pred, const float* gt, float* out, float* dpred, float dloss, long n, float* workspace, hipStream_t stream);
+int tatt_softmax_rows(const float* z, float* out, int R, int K, hipStream_t stream);
 size_t tatt_semantic_loss_workspace(int R);
 int tatt_semantic_loss(const float* zs, const float* zt, float* out, float* dzs, float dloss, int R, int K, float* workspace, hipStream_t stream);
 

@@ -109,6 +109,41 @@ def crnn_forward(P: Params, gray: Tensor, training: bool = False, inter: dict | 
     return out
 
 
+def semantic_loss(pred: Tensor, gt: Tensor) -> Tensor:
+    """SemanticLoss.forward loss/semantic_loss.py:21-38 (lambda1 = lambda2 = 1)."""
+    return (gt - pred).abs().mean() + torch.nn.KLDivLoss()(torch.log(pred + 1e-20), gt + 1e-20)
+
+
+def full_train_step(P_sr: Params, P_t: Params, P_s: Params, lr_img: Tensor, hr_img: Tensor, st_sr: dict, st_s: dict, step: int,
+                    arc: Tensor | None = None, lr_tpg: float = 1e-4):
+    """One iteration of TextSR.train (interfaces/super_resolution_eng.py:214-279) with dropout off:
+    teacher / student priors, SR forward on the detached student prior, L_SR (+ L_TSC when `arc` is given) + L_TP*100,
+    backward, clip_grad_norm_(SR params, 0.25), Adam(SR lr 1e-3, student lr 1e-4, betas (0.5, 0.999))."""
+    from oracle import tatt_ref as R
+    for P in (P_sr, P_s):
+        for v in P.values():
+            if v.is_floating_point() and v.requires_grad:
+                v.grad = None
+    with torch.no_grad():
+        label_vecs_hr = torch.softmax(crnn_forward(P_t, parse_crnn_data(hr_img), training=False), -1)
+    logits = crnn_forward(P_s, parse_crnn_data(lr_img), training=True)
+    label_vecs = torch.softmax(logits, -1)
+    prior = label_vecs.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2).detach()
+    loss_tp = semantic_loss(label_vecs, label_vecs_hr) * 100
+    if arc is None:
+        sr = R.tsrn_forward(P_sr, lr_img, prior, training=True)
+        loss_img, loss_tssim = R.image_loss(sr, hr_img).mean() * 100, torch.zeros(())
+    else:
+        loss_img, loss_tssim, sr, _ = R.tsc_losses(P_sr, lr_img, hr_img, prior, arc)
+    (loss_img + loss_tssim + loss_tp).backward()
+    sr_params = [v for v in P_sr.values() if v.is_floating_point() and v.requires_grad]
+    s_params = [v for v in P_s.values() if v.is_floating_point() and v.requires_grad]
+    with torch.no_grad():
+        total = R.clip_and_adam(sr_params, [p.grad for p in sr_params], st_sr, step)
+        R.clip_and_adam(s_params, [p.grad for p in s_params], st_s, step, lr=lr_tpg, max_norm=float("inf"))
+    return loss_img.detach(), loss_tssim.detach(), loss_tp.detach(), total, sr.detach()
+
+
 def text_prior(logits: Tensor) -> Tensor:
     """label_vecs_final of the trainer (interfaces/super_resolution_eng.py:227-231): softmax over classes, [T,B,K] ->
     the [B,K,1,T] view that TSRN_TL_TRANS.forward takes."""

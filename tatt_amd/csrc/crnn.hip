@@ -322,6 +322,34 @@ __global__ void semantic_loss_k(const float* __restrict__ zs, const float* __res
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// SemanticLoss on probabilities as the reference module takes them (pred_vec, gt_vec): no softmax; dpred = dscale * d loss/d pred
+__global__ void semantic_loss_probs_k(const float* __restrict__ pred, const float* __restrict__ gt, float* __restrict__ partial,
+                                      float* __restrict__ dpred, float dscale, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float tot = 0.f;
+  if (i < n) {
+    const float p = pred[i], g = gt[i];
+    tot = fabsf(g - p) + (g + 1e-20f) * (logf(g + 1e-20f) - logf(p + 1e-20f));
+    if (dpred) dpred[i] = dscale * ((p > g ? 1.f : (p < g ? -1.f : 0.f)) - (g + 1e-20f) / (p + 1e-20f));
+  }
+  __shared__ float red[4];
+  tot = wave_sum(tot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[r][:] = softmax(z[r][:]) (the text prior label_vecs = softmax(logits, -1), interfaces/super_resolution_eng.py:227)
+__global__ void softmax_rows_k(const float* __restrict__ z, float* __restrict__ out, int R, int K) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* a = z + (long)r * K;
+  float m = -INFINITY, s = 0.f;
+  for (int k = 0; k < K; ++k) m = fmaxf(m, a[k]);
+  for (int k = 0; k < K; ++k) s += expf(a[k] - m);
+  for (int k = 0; k < K; ++k) out[(long)r * K + k] = expf(a[k] - m) / s;
+}
+
 __global__ void semantic_final_k(const float* __restrict__ partial, int n, float scale, float* __restrict__ out) {
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
@@ -399,6 +427,27 @@ int tatt_maxpool_gen_bwd(const float* x, const float* dy, float* dx, int B, int 
 }
 
 size_t tatt_semantic_loss_workspace(int R) { return (size_t)cdiv(R, 256); }
+
+// SemanticLoss.forward(pred_vec, gt_vec) on probabilities (n elements): out[0] = loss, dpred (optional) = dloss * dloss/dpred.
+// workspace: ceil(n / 256) floats.
+int tatt_semantic_loss_probs(const float* pred, const float* gt, float* out, float* dpred, float dloss, long n, float* workspace,
+                             hipStream_t st) {
+  TATT_CHECK_ARG(pred && gt && out && workspace && n > 0, "tatt_semantic_loss_probs: bad arguments");
+  const int nb = cdiv(n, 256);
+  const float inv = 1.f / (float)n;
+  hipLaunchKernelGGL(semantic_loss_probs_k, dim3(nb), dim3(256), 0, st, pred, gt, workspace, dpred, dloss * inv, n);
+  TATT_LAUNCH_CHECK("semantic_loss_probs");
+  hipLaunchKernelGGL(semantic_final_k, dim3(1), dim3(64), 0, st, workspace, nb, inv, out);
+  TATT_LAUNCH_CHECK("semantic_final");
+  return TATT_OK;
+}
+
+int tatt_softmax_rows(const float* z, float* out, int R, int K, hipStream_t st) {
+  TATT_CHECK_ARG(z && out && R > 0 && K > 0, "tatt_softmax_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_rows_k, dim3(cdiv(R, 256)), dim3(256), 0, st, z, out, R, K);
+  TATT_LAUNCH_CHECK("softmax_rows");
+  return TATT_OK;
+}
 
 // out[0] = SemanticLoss(softmax(zs), softmax(zt)); if dzs: dzs = dloss * d out / d zs (zt, the teacher, takes no gradient)
 int tatt_semantic_loss(const float* zs, const float* zt, float* out, float* dzs, float dloss, int R, int K, float* workspace,

@@ -157,6 +157,10 @@ class SRTrainer:
         import math
         return (torch.rand(B) * 2 - 1) * self.tssim_rotation_degree / 180.0 * math.pi
 
+    def extra_grad_buffers(self):
+        """Gradient buffers besides flat_g that a data-parallel step must all-reduce (subclasses)."""
+        return []
+
     def _update(self):
         self.L.clip_adam(self.flat_p, self.flat_g, self.m, self.v, self.n, self.lr, self.betas[0], self.betas[1], self.eps,
                          self.max_norm, self.state, self.ws)
@@ -197,9 +201,83 @@ class SRTrainer:
         self.graph.replay()
         if self.dp:
             works = [allreduce_mean(self.flat_g[a:b], async_op=True) for a, b in self.bucket_range]
+            works += [allreduce_mean(t, async_op=True) for t in self.extra_grad_buffers()]
             for w in works:
                 if w is not None:
                     w.wait()
             self._update()
         self.steps += 1
         return self.per
+
+
+class TATTTrainer(SRTrainer):
+    """The reference's whole training iteration (interfaces/super_resolution_eng.py:214-279) as one fused step:
+
+        teacher prior   label_vecs_hr = softmax(CRNN_fixed(parse_crnn_data(HR)))            (:220-222, no gradient)
+        student prior   label_vecs    = softmax(CRNN_student(parse_crnn_data(LR)))          (:226-228)
+        L_SR (+ L_TSC)  SR(LR, label_vecs.detach()) -> ImageLoss*100 (+ TRI_SSIM term)      (:233-262)   [SRTrainer]
+        L_TP            SemanticLoss(label_vecs, label_vecs_hr) * 100                       (:240)
+        clip_grad_norm_(SR parameters, 0.25); Adam over two groups: SR lr, student lr_tpg   (:277-279, base.py:217-237)
+
+    The student's gradient comes from L_TP only (the SR net takes its prior detached), so the two backward passes are
+    independent; its Adam step is not clipped (the reference clips `model_list` = the SR net only)."""
+
+    def __init__(self, model, teacher, student, lr=1e-3, lr_tpg=1e-4, **kw):
+        super().__init__(model, lr=lr, **kw)
+        self.teacher, self.student, self.lr_tpg = teacher.eval(), student, lr_tpg
+        named = list(student.named_parameters())
+        dev = self.flat_p.device
+        n, offs = 0, {}
+        for k, p in named:
+            offs[k] = n
+            n += (p.numel() + 63) // 64 * 64
+        self.n_s = n
+        self.s_p, self.s_g = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        self.s_m, self.s_v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        self.s_state, self.s_ws = torch.zeros(8, device=dev), torch.empty(1024, device=dev)
+        self.G_s = {}
+        for k, p in named:
+            sl = slice(offs[k], offs[k] + p.numel())
+            self.s_p[sl].copy_(p.data.reshape(-1).float())
+            p.data = self.s_p[sl].view(p.shape)
+            self.G_s[k] = self.s_g[sl].view(p.shape)
+            p.grad = self.G_s[k]
+        if self.dp:
+            dist.broadcast(self.s_p, 0)
+            for b in student.buffers():
+                dist.broadcast(b, 0)
+        self.loss_tp = None                                    # device scalar: SemanticLoss of the last step (L_TP = 100 x)
+
+    def _fwd_bwd(self, lr_img, hr_img, tp, overlap, arc=None):
+        """`tp` is ignored: the prior comes from the student CRNN."""
+        L, B = self.L, lr_img.shape[0]
+        K = self.student.nclass
+        with torch.no_grad():
+            logits_t = self.teacher.forward_from_images(hr_img)                          # [26, B, K]
+        plan = self.student.plan()
+        x4 = torch.empty(B, 32, 100, 4, device=lr_img.device)
+        L.crnn_prep(lr_img, x4, B, lr_img.shape[1], lr_img.shape[2], lr_img.shape[3], 32, 100)
+        logits_s, ctx_s = plan.forward(x4, B, 100, True, want_ctx=True)
+        T = logits_s.shape[0]
+        probs = torch.empty(T, B, K, device=lr_img.device)
+        L.softmax_rows(logits_s, probs, T * B, K)
+        prior = probs.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)                 # label_vecs_final: the [B,K,1,26] view
+        per, works = super()._fwd_bwd(lr_img, hr_img, prior, overlap, arc=arc)
+        # L_TP and the student's backward pass
+        self.s_g.zero_()
+        self.loss_tp = torch.empty(1, device=lr_img.device)
+        dz = torch.empty(T * B, K, device=lr_img.device)
+        ws = torch.empty(L.semantic_loss_workspace(T * B), device=lr_img.device)
+        L.semantic_loss(logits_s, logits_t, self.loss_tp, dz, 100.0, T * B, K, ws)
+        plan.backward(ctx_s, dz.view(T, B, K), self.G_s)
+        if overlap:
+            works.append(allreduce_mean(self.s_g, async_op=True))
+        return per, works
+
+    def extra_grad_buffers(self):
+        return [self.s_g]
+
+    def _update(self):
+        super()._update()
+        self.L.clip_adam(self.s_p, self.s_g, self.s_m, self.s_v, self.n_s, self.lr_tpg, self.betas[0], self.betas[1], self.eps,
+                         1e30, self.s_state, self.s_ws)                                  # max_norm = inf: the student is not clipped

@@ -135,3 +135,47 @@ def test_host_mirrors_tri_ssim_and_rotation_autograd():
     assert rel_l2(bg.grad.cpu().double().numpy(), bd.grad.numpy()) < 1e-3
     assert abs(float(SSIM()(a.cuda(), c.cuda())) - float(R.ssim(a.double(), c.double()))) < 2e-6
     assert abs(float(calculate_psnr(a.cuda(), c.cuda())) - float(R.psnr(a.double(), c.double()))) < 1e-4
+
+
+def _crnn(seed, train):
+    from tatt_amd.model.crnn import CRNN
+    m = CRNN()
+    st = procgen.fill_state(m.state_dict(), seed=seed)
+    m.load_state_dict(st, strict=True)
+    return m.cuda().train(train), st
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_full_reference_iteration_matches_oracle(graph):
+    """TATTTrainer = the reference's whole train() iteration (teacher + student CRNN priors, SR step, SemanticLoss,
+    two-group Adam) against the oracle's fp64 statement of interfaces/super_resolution_eng.py:214-279."""
+    from oracle import crnn_ref as C
+    from tatt_amd.trainer import TATTTrainer
+    B = 3
+    state = make_state(37, seed=12)
+    m = build(state)
+    m.dropout_p = 0.0
+    teacher, st_t = _crnn(21, False)
+    student, st_s = _crnn(22, True)
+    tr = TATTTrainer(m, teacher, student, use_graph=graph)
+    hr, lr, tp = procgen.make_inputs(B, 37, seed=13)
+    per = tr.step(lr.cuda(), hr.cuda(), tp.cuda())
+    torch.cuda.synchronize()
+    dbl = lambda st, buf: {k: (v.double().requires_grad_(True) if v.is_floating_point() and not buf(k) else
+                               (v.double() if v.is_floating_point() else v.clone())) for k, v in st.items()}
+    P_sr = dbl(state, is_buffer)
+    P_t = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in st_t.items()}
+    P_s = dbl(st_s, lambda k: "running_" in k)
+    loss_img, _, loss_tp, total, _ = C.full_train_step(P_sr, P_t, P_s, lr.double(), hr.double(), {}, {}, 1)
+    assert abs(float(per.mean()) * 100 - float(loss_img)) < 5e-5 * float(loss_img)
+    assert abs(float(tr.loss_tp) * 100 - float(loss_tp)) < 1e-4 * float(loss_tp)
+    assert abs(float(tr.state[0]) - float(total)) < 5e-3 * float(total)
+    sd_s, sd_t = student.state_dict(), teacher.state_dict()
+    for k in ["rnn.1.embedding.weight", "rnn.0.rnn.weight_hh_l0", "cnn.conv6.weight", "cnn.conv3.weight", "cnn.batchnorm2.weight"]:
+        d_gpu = (sd_s[k].cpu().double() - st_s[k].double()).numpy().ravel()
+        d_ref = (P_s[k].detach() - st_s[k].double()).numpy().ravel()
+        assert np.mean(np.sign(d_gpu) == np.sign(d_ref)) > 0.99, k                  # first Adam step ~ -lr_tpg * sign(g)
+        assert abs(np.abs(d_gpu).mean() - 1e-4) < 2e-5, k                           # student group runs at lr 1e-4
+    for k, v in st_t.items():
+        assert torch.equal(sd_t[k].cpu(), v), f"teacher changed: {k}"
+    assert int(sd_s["cnn.batchnorm4.num_batches_tracked"]) == (2 if graph else 1)    # the graph path warms up once before capture
