@@ -153,11 +153,19 @@ int tatt_transpose(const float* in, float* out, int rows, int cols, hipStream_t 
 int tatt_maxpool_gen_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW, hipStream_t stream);
 /* SemanticLoss (loss/semantic_loss.py:21-38: mean |gt - pred| + KLDivLoss()(log(pred + 1e-20), gt + 1e-20)) fused with the two
  * softmaxes of the trainer (interfaces/super_resolution_eng.py:222-228,:240): zs / zt = student / teacher logits [R = T*B, K];
- * out[0] = loss; if dzs != NULL, dzs = dloss * d loss / d zs.  workspace: tatt_semantic_loss_workspace(R) floats. */
-int tatt_semantic_loss_probs(const float* pred, const float* gt, float* out, float* dpred, float dloss, long n, float* workspace, hipStream_t stream);
-int tatt_softmax_rows(const float* z, float* out, int R, int K, hipStream_t stream);
+ * out[0] = loss; if dzs != NULL, dzs = dloss * d loss / d zs.  workspace: tatt_semantic_loss_workspace(R) floats.
+ * tatt_semantic_loss_probs is the module form on probabilities (pred, gt of n elements; dpred optional), and
+ * tatt_softmax_rows the prior itself, label_vecs = softmax(logits, -1) (super_resolution_eng.py:227). */
 size_t tatt_semantic_loss_workspace(int R);
 int tatt_semantic_loss(const float* zs, const float* zt, float* out, float* dzs, float dloss, int R, int K, float* workspace, hipStream_t stream);
+int tatt_semantic_loss_probs(const float* pred, const float* gt, float* out, float* dpred, float dloss, long n, float* workspace, hipStream_t stream);
+int tatt_softmax_rows(const float* z, float* out, int R, int K, hipStream_t stream);
+/* Greedy CTC decode of get_string_crnn (utils/metrics.py:128-146) on logits [T][B][K]: arg [B][T] = per-step argmax (first
+ * index on ties, like torch.max), codes [B][T] / lens [B] = the class indices left after merging runs and dropping blank 0. */
+int tatt_ctc_greedy(const float* logits, int* arg, int* codes, int* lens, int T, int B, int K, hipStream_t stream);
+/* F.interpolate(x, (OH, OW), mode="bicubic") on `planes` = B*C contiguous [H][W] planes: the LR image at SR size for the
+ * psnr_lr / ssim_lr metrics of the eval loop (interfaces/super_resolution_eng.py:486). */
+int tatt_bicubic_resize(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t stream);
 
 /* ---- ImageLoss = MSE + gradient-prior L1 (loss/image_loss.py:19-32, :40-56), NCHW ------------------------- */
 int tatt_image_loss_fwd(const float* sr, const float* hr, float* per, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);

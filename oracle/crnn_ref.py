@@ -144,6 +144,59 @@ def full_train_step(P_sr: Params, P_t: Params, P_s: Params, lr_img: Tensor, hr_i
     return loss_img.detach(), loss_tssim.detach(), loss_tp.detach(), total, sr.detach()
 
 
+ALPHABET = "-0123456789abcdefghijklmnopqrstuvwxyz"
+
+
+def get_string_crnn(outputs: Tensor, alphabet: str = ALPHABET) -> list:
+    """utils/metrics.py:128-146: per-step argmax, merge runs of equal characters, a blank (class 0) ends a run and is dropped.
+    Pinned by tests/golden/ctc_strings.json (made from the reference function)."""
+    res = []
+    for idx in outputs.permute(1, 0, 2).argmax(-1).tolist():
+        s, last = "", None
+        for i in idx:
+            ch = alphabet[i]
+            if i == 0:
+                last = None
+            elif ch != last:
+                s += ch
+                last = ch
+        res.append(s)
+    return res
+
+
+def str_filt(s: str, voc: str) -> str:
+    """utils/util.py:14-42 for a vocabulary given as a string / list of allowed characters."""
+    return "".join(c for c in s.lower() if c in voc)
+
+
+def eval_batches(P_sr: Params, P_stu: Params, P_rec: Params, batches) -> dict:
+    """TextSR.eval (interfaces/super_resolution_eng.py:375-552, test_model == 'crnn') on stock torch: per-batch PSNR / SSIM of
+    SR and bicubic LR vs HR (channels 0..2), greedy strings of LR / HR / SR, accuracies after str_filt('lower')."""
+    from oracle import tatt_ref as R
+    voc = "0123456789abcdefghijklmnopqrstuvwxyz"
+    md = {"psnr": [], "ssim": [], "psnr_lr": [], "ssim_lr": [], "strings_sr": [], "strings_lr": [], "strings_hr": []}
+    n = {"sr": 0, "lr": 0, "hr": 0}
+    tot = 0
+    with torch.no_grad():
+        for hr, lr, labels in batches:
+            prior = text_prior(crnn_forward(P_stu, parse_crnn_data(lr), training=False))
+            sr = R.tsrn_forward(P_sr, lr, prior, training=False)
+            for tag, img in (("lr", lr), ("hr", hr), ("sr", sr)):
+                strs = get_string_crnn(crnn_forward(P_rec, parse_crnn_data(img), training=False))
+                md["strings_" + tag] += strs
+                n[tag] += sum(str_filt(s, voc) == str_filt(l, voc) for s, l in zip(strs, labels))
+            up = F.interpolate(lr, sr.shape[-2:], mode="bicubic")
+            md["psnr"].append(R.psnr(sr[:, :3], hr[:, :3]))
+            md["ssim"].append(R.ssim(sr[:, :3], hr[:, :3]))
+            md["psnr_lr"].append(R.psnr(up[:, :3], hr[:, :3]))
+            md["ssim_lr"].append(R.ssim(up[:, :3], hr[:, :3]))
+            tot += lr.shape[0]
+    md["accuracy"], md["accuracy_lr"], md["accuracy_hr"] = (round(n[k] / tot, 4) for k in ("sr", "lr", "hr"))
+    md["psnr_avg"] = round(float(sum(md["psnr"]) / (len(md["psnr"]) + 1e-10)), 6)
+    md["ssim_avg"] = round(float(sum(md["ssim"]) / (len(md["psnr"]) + 1e-10)), 6)
+    return md
+
+
 def text_prior(logits: Tensor) -> Tensor:
     """label_vecs_final of the trainer (interfaces/super_resolution_eng.py:227-231): softmax over classes, [T,B,K] ->
     the [B,K,1,T] view that TSRN_TL_TRANS.forward takes."""

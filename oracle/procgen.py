@@ -80,3 +80,23 @@ def make_inputs(B: int, K: int = 37, seed: int = 0, H: int = 16, W: int = 64):
     logits = 3.0 * r.standard_normal((B, 26, K)).astype(np.float32)
     tp = torch.softmax(torch.from_numpy(logits), -1).permute(0, 2, 1).unsqueeze(2).contiguous()  # [B,K,1,26]
     return torch.from_numpy(hr), torch.from_numpy(lr), tp
+
+
+def planted_logits(seed: int, T: int = 26, B: int = 16, K: int = 37):
+    """Recogniser logits [T,B,K] whose per-step argmax follows a planted class sequence with runs and blanks, plus exact ties at
+    every fourth step (the first index must win).  Returns (logits float32 ndarray, planted indices [T,B])."""
+    rng = np.random.RandomState(seed)
+    idx = np.zeros((T, B), np.int64)
+    for b in range(B):
+        t = 0
+        while t < T:
+            c = 0 if rng.rand() < 0.35 else rng.randint(1, K)
+            run = rng.randint(1, 4)
+            idx[t:t + run, b] = c
+            t += run
+    x = rng.randn(T, B, K).astype(np.float32)
+    x[np.arange(T)[:, None], np.arange(B)[None, :], idx] = 9.0
+    tie = (idx + 5) % K
+    tt, bb = np.nonzero((np.arange(T)[:, None] % 4 == 0) & np.ones((1, B), bool))
+    x[tt, bb, tie[tt, bb]] = 9.0
+    return x, idx

@@ -49,6 +49,32 @@ __global__ void crnn_prep_k(const float* __restrict__ x, float* __restrict__ y, 
   *reinterpret_cast<float4*>(y + (long)i * 4) = make_float4(0.299f * ch[0] + 0.587f * ch[1] + 0.114f * ch[2], 0.f, 0.f, 0.f);
 }
 
+// F.interpolate(x, (OH, OW), mode="bicubic") on P = B*C planes (the LR image brought to SR size for the psnr_lr / ssim_lr
+// metrics, interfaces/super_resolution_eng.py:486)
+__global__ void bicubic_planes_k(const float* __restrict__ x, float* __restrict__ y, int P, int H, int W, int OH, int OW) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)P * OH * OW) return;
+  const int ox = i % OW, oy = (i / OW) % OH;
+  const long pl = i / ((long)OW * OH);
+  const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+  const float ry = sh * (oy + 0.5f) - 0.5f, rx = sw * (ox + 0.5f) - 0.5f;
+  const int iy = (int)floorf(ry), ix = (int)floorf(rx);
+  float wy[4], wx[4];
+  cubic_coeffs(ry - iy, wy);
+  cubic_coeffs(rx - ix, wx);
+  const float* p = x + pl * H * W;
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int yy = min(max(iy - 1 + r, 0), H - 1);
+    float row = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) row += wx[q] * p[yy * W + min(max(ix - 1 + q, 0), W - 1)];
+    acc += wy[r] * row;
+  }
+  y[i] = acc;
+}
+
 // ---- MaxPool2d(kernel, stride, padding), NHWC; padded positions never win (torch pads with -inf) -----------------------
 __global__ void maxpool_gen_k(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int KH, int KW, int SH,
                               int SW, int PH, int PW, int OH, int OW) {
@@ -357,9 +383,56 @@ __global__ void semantic_final_k(const float* __restrict__ partial, int n, float
   if (threadIdx.x == 0) out[0] = s * scale;
 }
 
+// Greedy CTC decode of get_string_crnn (utils/metrics.py:128-146): one wave per sample b.  arg[b][t] = argmax_k x[t][b][k]
+// (first index on ties, as torch.max); codes[b][0..lens[b]) = the indices left after merging runs and dropping blank 0.
+__global__ __launch_bounds__(64) void ctc_greedy_k(const float* __restrict__ x, int* __restrict__ arg, int* __restrict__ codes,
+                                                   int* __restrict__ lens, int T, int B, int K) {
+  const int b = blockIdx.x, l = threadIdx.x;
+  int last = 0, n = 0;
+  for (int t = 0; t < T; ++t) {
+    const float* r = x + ((long)t * B + b) * K;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = l; k < K; k += 64) {
+      const float v = r[k];
+      if (v > bv) { bv = v; bi = k; }
+    }
+    for (int o = 32; o; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (bi == 0x7fffffff) bi = 0;
+    if (l == 0) {
+      arg[b * T + t] = bi;
+      if (bi != last && bi != 0) codes[b * T + n++] = bi;
+      last = bi;
+    }
+  }
+  if (l == 0) {
+    lens[b] = n;
+    for (int i = n; i < T; ++i) codes[b * T + i] = 0;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int tatt_bicubic_resize(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t st) {
+  TATT_CHECK_ARG(x && y && planes > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "tatt_bicubic_resize: bad arguments");
+  TATT_CHECK_ARG((long)planes * OH * OW < (1L << 31) * 256, "tatt_bicubic_resize: too large");
+  hipLaunchKernelGGL(bicubic_planes_k, dim3(cdiv((long)planes * OH * OW, 256)), dim3(256), 0, st, x, y, planes, H, W, OH, OW);
+  TATT_LAUNCH_CHECK("bicubic_resize");
+  return TATT_OK;
+}
+
+int tatt_ctc_greedy(const float* logits, int* arg, int* codes, int* lens, int T, int B, int K, hipStream_t st) {
+  TATT_CHECK_ARG(logits && arg && codes && lens && T > 0 && B > 0 && K > 0, "tatt_ctc_greedy: bad arguments");
+  hipLaunchKernelGGL(ctc_greedy_k, dim3(B), dim3(64), 0, st, logits, arg, codes, lens, T, B, K);
+  TATT_LAUNCH_CHECK("ctc_greedy");
+  return TATT_OK;
+}
 
 // parse_crnn_data: x [B,Ctot>=3,H,W] NCHW in [0,1] -> y [B,OH,OW,4] NHWC (channel 0 = gray, 1..3 = 0)
 int tatt_crnn_prep(const float* x, float* y, int B, int Ctot, int H, int W, int OH, int OW, hipStream_t st) {

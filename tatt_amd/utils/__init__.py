@@ -1,1 +1,1 @@
-from . import ssim_psnr  # noqa: F401
+from . import metrics, ssim_psnr, util  # noqa: F401

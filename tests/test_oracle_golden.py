@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/tatt_ref.py) to golden vectors produced by the REAL reference modules
 (tests/golden/make_golden.py, run where /root/reference exists).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -119,3 +121,25 @@ def test_crnn_oracle_vs_reference_golden(name, train):
     if train:                                               # the reference ran hr then lr on ONE module: stats updated twice
         for k in ("cnn.batchnorm2.running_mean", "cnn.batchnorm6.running_var"):
             assert rel_l2(P[k].numpy(), gold["bn/" + k]) < 1e-6
+
+
+def test_ctc_decode_and_str_filt_vs_reference_golden():
+    """oracle get_string_crnn / str_filt and the product's host-side str_filt against strings produced by the reference's own
+    utils/metrics.get_string_crnn and utils/util.str_filt (tests/golden/make_golden_ctc.py)."""
+    import json
+    import string
+    from oracle import crnn_ref as C
+    from tatt_amd.utils.util import str_filt
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ctc_strings.json")))
+    for case in gold["cases"]:
+        x, idx = procgen.planted_logits(case["seed"])
+        assert idx.T.tolist() == case["planted"]
+        assert C.get_string_crnn(torch.from_numpy(x)) == case["strings"]
+    voc = {"digit": string.digits, "lower": string.digits + string.ascii_lowercase, "upper": string.digits + string.ascii_letters}
+    for f in gold["filt"]:
+        if f["mode"] in voc:                                  # the 40-character file of non-CRNN 'lower' holds the same characters
+            assert [C.str_filt(w, voc[f["mode"]]) for w in f["in"]] == f["out"]
+        if f["mode"] in ("digit", "upper") or (f["mode"] == "lower" and f["is_crnn"]):
+            assert [str_filt(w, f["mode"], f["is_crnn"]) for w in f["in"]] == f["out"]
+        elif os.path.isdir("/root/reference"):                # file-backed vocabularies: only where the reference checkout exists
+            assert [str_filt(w, f["mode"], f["is_crnn"], voc_root="/root/reference") for w in f["in"]] == f["out"]
