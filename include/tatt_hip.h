@@ -167,6 +167,15 @@ int tatt_ctc_greedy(const float* logits, int* arg, int* codes, int* lens, int T,
  * psnr_lr / ssim_lr metrics of the eval loop (interfaces/super_resolution_eng.py:486). */
 int tatt_bicubic_resize(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t stream);
 
+/* ---- input transform: resizeNormalize.__call__ (dataset/dataset.py:282-325) per sample of
+ * alignCollate.__call__ (:677-693) = PIL resize(BICUBIC) -> ToTensor -> mask channel (1 where L <= mean L), bit-exact with
+ * Pillow's integer resampler.  data = the batch's uint8 RGB images (HWC) packed in one device buffer, image b at byte
+ * offsets[b] with heights[b] x widths[b] pixels (device arrays); out [B][mask ? 4 : 3][OH][OW] float.  max_h / max_w bound the
+ * sizes in the batch (they size the LDS; a larger image yields NaNs in its slot).  tatt_resize_normalize_lds = the bytes of
+ * LDS one image then needs (<= 160 KB - 64 or the call is refused). */
+size_t tatt_resize_normalize_lds(int OH, int OW, int max_h, int max_w);
+int tatt_resize_normalize(const unsigned char* data, const long* offsets, const int* heights, const int* widths, float* out, int B, int OH, int OW, int mask, int max_h, int max_w, hipStream_t stream);
+
 /* ---- ImageLoss = MSE + gradient-prior L1 (loss/image_loss.py:19-32, :40-56), NCHW ------------------------- */
 int tatt_image_loss_fwd(const float* sr, const float* hr, float* per, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);
 int tatt_image_loss_bwd(const float* sr, const float* hr, const float* dper, float uniform, float* dsr, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);

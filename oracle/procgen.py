@@ -100,3 +100,21 @@ def planted_logits(seed: int, T: int = 26, B: int = 16, K: int = 37):
     tt, bb = np.nonzero((np.arange(T)[:, None] % 4 == 0) & np.ones((1, B), bool))
     x[tt, bb, tie[tt, bb]] = 9.0
     return x, idx
+
+
+def random_images(seed: int, n: int):
+    """n uint8 RGB arrays [h, w, 3] of TextZoom-like varied sizes (both larger and smaller than 32x128 / 16x64, plus the exact
+    target sizes so that the skipped-pass cases occur): smooth strokes + noise, procedurally generated."""
+    rng = np.random.RandomState(seed)
+    sizes = [(32, 128), (16, 64), (32, 90), (21, 128), (3, 5), (1, 1)]
+    while len(sizes) < n:
+        sizes.append((int(rng.randint(6, 120)), int(rng.randint(12, 420))))
+    out = []
+    for h, w in sizes[:n]:
+        yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        img = np.zeros((h, w, 3))
+        for c in range(3):
+            img[..., c] = 128 + 100 * np.sin(rng.uniform(0.05, 0.8) * xx + rng.uniform(0, 6)) * np.cos(rng.uniform(0.05, 0.9) * yy)
+        img += rng.randn(h, w, 3) * rng.choice([2.0, 25.0, 80.0])
+        out.append(np.clip(img, 0, 255).astype(np.uint8))
+    return out
