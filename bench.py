@@ -28,7 +28,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 matrix peak
 CONV_TRAFFIC_BYTES = 34.8e6          # profiles/r01_conv_traffic.md
 
 
-def conv_roofline(L, B, iters=10):
+def conv_roofline(L, B, iters=10, bf16=False):
     """Dominant kernel = gemm_kernel<OP_IM2COL, OP_CONVW_P, FAST>: the NHWC implicit-GEMM convolution (forward and
     dgrad) over per-step packed weights, 34 launches per training step.  Replays exactly that per-step launch mix
     (22 x SRB/block7 3x3 64->64 on [B,16,64], the 64<->256 up-sampling conv and its dgrad, 10 STN-head convs) so that
@@ -60,6 +60,13 @@ def conv_roofline(L, B, iters=10):
     dt = e0.elapsed_time(e1) / (iters * len(calls)) * 1e-3
     fl = flops / len(calls)
     ach = fl / dt / 1e12
+    if bf16:
+        # With bf16 operands the same launch is bound by moving its fp32 tensors, not by the matrix core (2.5 PFLOP/s dense):
+        # price it against HBM with the algorithmic bytes of an SRB-shaped launch scaled to the mix (in + out + weights, fp32).
+        byts = sum(4.0 * (c[4] * c[5] * c[6] * (c[7] + c[8]) + 9 * c[7] * c[8]) for c in calls) / len(calls)
+        return {"bound": "hbm", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST,BF16> (3x3 conv fwd+dgrad, per-step mix of %d launches)" % len(calls),
+                "achieved": round(byts / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byts / dt / 8e12, 4), "traffic": None,
+                "launch_us": round(dt * 1e6, 2), "bytes_per_launch": byts, "tflops": round(ach, 2), "launches_per_step": len(calls)}
     return {"bound": "mfma", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST> (3x3 conv fwd+dgrad, per-step mix of %d launches)" % len(calls),
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": CONV_TRAFFIC_BYTES, "traffic_note": "bytes per SRB-shaped launch (algorithmic 33.7e6): rocprofv3 --pmc 2*FETCH_SIZE"
@@ -98,6 +105,8 @@ def main():
                                                        "SemanticLoss, two-group Adam around the SR step (SURVEY §8f ranks 1-2)")
     ap.add_argument("--tsc", action="store_true", help="add the TSC term (second SR forward on rotated input + TRI_SSIM): "
                                                       "BASELINE config 3's step in fp32; off = config 2, the default metric")
+    ap.add_argument("--bf16", action="store_true", help="matrix-core operands in bf16 (fp32 accumulate, fp32 tensors in memory): "
+                                                       "with --tsc this is BASELINE config 3's arithmetic; off = fp32, the default metric")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,6 +124,7 @@ def main():
     from tatt_amd.model.tsrn import TSRN_TL_TRANS
     from tatt_amd.trainer import SRTrainer
 
+    lib().set_matmul_precision(1 if a.bf16 else 0)
     torch.manual_seed(123)
     model = TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32,
                           text_embedding=a.K)
@@ -151,23 +161,26 @@ def main():
 
     if rank == 0:
         ms = dt / a.steps * 1e3
+        prec = "bf16" if a.bf16 else "fp32"
         value = a.batch * world * a.steps / dt
         out = {
             "metric": "train images/sec (whole node) TATT 16x64->32x128", "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("whole reference iteration in fp32: CRNN teacher + student priors, SR step%s, SemanticLoss, "
-                                    "two-group Adam, K=%d" % (" + TSC" if a.tsc else "", a.K)) if a.full else
-                                   ("BASELINE config 3 step in fp32 (config 2 + TSC: second SR forward on the rotated input, "
-                                    "TRI_SSIM x10), K=%d" % a.K) if a.tsc else
-                                   "BASELINE config 2: TSRN_TL_TRANS(STN, K=%d) single training step fp32, pixel+gradient loss, "
-                                   "clip 0.25 + Adam, frozen text prior" % a.K,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bf16 else "f32", "data": "synthetic",
+            "config": {"workload": ("whole reference iteration in %s: CRNN teacher + student priors, SR step%s, SemanticLoss, "
+                                    "two-group Adam, K=%d" % (prec, " + TSC" if a.tsc else "", a.K)) if a.full else
+                                   ("BASELINE config 3 step in %s (config 2 + TSC: second SR forward on the rotated input, "
+                                    "TRI_SSIM x10), K=%d" % (prec, a.K)) if a.tsc else
+                                   "BASELINE config 2: TSRN_TL_TRANS(STN, K=%d) single training step %s, pixel+gradient loss, "
+                                   "clip 0.25 + Adam, frozen text prior" % (a.K, prec),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "lr_shape": [4, 16, 64], "hr_shape": [4, 32, 128],
-                       "parallelism": f"dp{world}", "hip_graph": not a.no_graph, "loss": round(loss, 4)},
+                       "parallelism": f"dp{world}", "hip_graph": not a.no_graph, "loss": round(loss, 4),
+                       **({"precision": "bf16 MFMA operands (round-to-nearest-even), fp32 accumulate; tensors in HBM, recurrences, "
+                                        "norms, losses and optimiser fp32"} if a.bf16 else {})},
             "model_tflops": round(value * FLOP_PER_IMAGE_TRAIN * (2 if a.tsc else 1) / 1e12, 2),
             "model_frac_of_f32_mfma_peak": round(value * FLOP_PER_IMAGE_TRAIN * (2 if a.tsc else 1) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
         }
-        out["roofline"] = conv_roofline(lib(), a.batch)
+        out["roofline"] = conv_roofline(lib(), a.batch, bf16=a.bf16)
         if world == 1 and not a.no_cpu_baseline and not a.tsc and not a.full:
             out["cpu_baseline"] = cpu_baseline(state_cpu, a.batch, a.K)
         print(json.dumps(out), flush=True)

@@ -167,6 +167,14 @@ int tatt_ctc_greedy(const float* logits, int* arg, int* codes, int* lens, int T,
  * psnr_lr / ssim_lr metrics of the eval loop (interfaces/super_resolution_eng.py:486). */
 int tatt_bicubic_resize(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t stream);
 
+/* ---- matrix-core precision (no counterpart in the reference, which has no autocast; BASELINE.json config 3 asks for a bf16
+ * step).  Process-wide switch read by tatt_gemm / tatt_conv_fwd* / tatt_conv_wgrad at launch time: 0 = fp32 operands on
+ * v_mfma_f32_32x32x2_f32 (default, the parity path), 1 = operands rounded to bf16 (nearest-even) on their way into
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulation; tensors in memory, the recurrent kernels, normalisations, losses and the
+ * optimiser stay fp32.  Launches whose shapes take the generic (non-FAST) loaders stay fp32 in both modes. */
+int tatt_set_matmul_precision(int mode);
+int tatt_get_matmul_precision(void);
+
 /* ---- input transform: resizeNormalize.__call__ (dataset/dataset.py:282-325) per sample of
  * alignCollate.__call__ (:677-693) = PIL resize(BICUBIC) -> ToTensor -> mask channel (1 where L <= mean L), bit-exact with
  * Pillow's integer resampler.  data = the batch's uint8 RGB images (HWC) packed in one device buffer, image b at byte

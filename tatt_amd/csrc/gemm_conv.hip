@@ -120,8 +120,24 @@ __device__ __forceinline__ void split_pixel(int k0, int off, int H, int W, int& 
 // scalar (buffer_load soffset), predication is a v_cndmask to an out-of-range offset.  This matters more than anything
 // else in the kernel: on gfx950 VALU instructions do not overlap with MFMA on a SIMD (tools/exp_mfma_lds.hip: 180 extra
 // VALU ops per 16-MFMA tile drop 134 TFLOP/s to 82), so loader arithmetic is paid in MFMA issue slots.
-template <int AOP, int BOP, bool FAST>
+//
+// BF16 (FAST only; tatt_set_matmul_precision(1)): the operands are rounded to bf16 (round-to-nearest-even) on their way into
+// the matrix core and multiplied with v_mfma_f32_32x32x16_bf16, accumulating in fp32; global memory stays fp32.  k-contiguous
+// images are stored in LDS as bf16 ([row][32 k] = 64 B per row, the 16-byte k-group c at position c ^ ((row >> 1) & 3): four
+// even and four odd consecutive rows cover all 32 banks), one ds_read_b128 per operand per MFMA; row-contiguous images stay
+// fp32 in LDS and are packed when read.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  bf16x2 r = __builtin_convertvector(v, bf16x2);
+  return *reinterpret_cast<unsigned*>(&r);
+}
+
+template <int AOP, int BOP, bool FAST, bool BF16 = false>
 __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
+  static_assert(FAST || !BF16, "the bf16 path exists for the FAST loaders only");
   __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -404,6 +420,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   };
 
   const int st_swz = (kq ^ (r0 & 7)) * 4;  // rows r0 and r0 + 64 share r0 & 7
+  const int st_swz16 = (((kq >> 1) ^ ((r0 >> 1) & 3)) << 4) + ((kq & 1) << 3);  // bf16 image: byte offset of k = 4 kq inside the row
   auto store_tiles = [&](int buf, const float4 (&ra)[2], const float4& rb) {
     float* As = lds + buf * (A_FLOATS + B_FLOATS);
     float* Bs = As + A_FLOATS;
@@ -411,12 +428,19 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         *reinterpret_cast<float4*>(As + ((tid >> 5) + 16 * j) * LDA_M + (tid & 31) * 4) = ra[j];
+    } else if constexpr (BF16) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(As) + (r0 + 64 * j) * 64 + st_swz16) =
+            make_uint2(pack_bf16(ra[j].x, ra[j].y), pack_bf16(ra[j].z, ra[j].w));
     } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(As + (r0 + 64 * j) * LDK + st_swz) = ra[j];
     }
     if constexpr (BOP == OP_ROWCONTIG || BOP == OP_IM2COL_N) {
       *reinterpret_cast<float4*>(Bs + (tid >> 4) * LDB_N + (tid & 15) * 4) = rb;
+    } else if constexpr (BF16) {
+      *reinterpret_cast<uint2*>(reinterpret_cast<char*>(Bs) + r0 * 64 + st_swz16) = make_uint2(pack_bf16(rb.x, rb.y), pack_bf16(rb.z, rb.w));
     } else {
       *reinterpret_cast<float4*>(Bs + r0 * LDK + st_swz) = rb;
     }
@@ -429,6 +453,30 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   auto compute = [&](int cur) {
     const float* As = lds + cur * (A_FLOATS + B_FLOATS);
     const float* Bs = As + A_FLOATS;
+    if constexpr (BF16) {
+#pragma unroll
+      for (int g = 0; g < BK / 16; ++g) {  // lane half lh supplies k = 16 g + 8 lh .. + 7 of its row, for A and B alike
+        uint4 au, bu;
+        if constexpr (AOP == OP_ROWCONTIG || AOP == OP_IM2COL_M) {
+          const float* p = As + (g * 16 + 8 * lh) * LDA_M + wm * 32 + li;
+          au = make_uint4(pack_bf16(p[0], p[LDA_M]), pack_bf16(p[2 * LDA_M], p[3 * LDA_M]), pack_bf16(p[4 * LDA_M], p[5 * LDA_M]),
+                          pack_bf16(p[6 * LDA_M], p[7 * LDA_M]));
+        } else {
+          const int row = wm * 32 + li;
+          au = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(As) + row * 64 + (((2 * g + lh) ^ ((row >> 1) & 3)) << 4));
+        }
+        if constexpr (BOP == OP_ROWCONTIG || BOP == OP_IM2COL_N) {
+          const float* p = Bs + (g * 16 + 8 * lh) * LDB_N + wn * 32 + li;
+          bu = make_uint4(pack_bf16(p[0], p[LDB_N]), pack_bf16(p[2 * LDB_N], p[3 * LDB_N]), pack_bf16(p[4 * LDB_N], p[5 * LDB_N]),
+                          pack_bf16(p[6 * LDB_N], p[7 * LDB_N]));
+        } else {
+          const int row = wn * 32 + li;
+          bu = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Bs) + row * 64 + (((2 * g + lh) ^ ((row >> 1) & 3)) << 4));
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&au), *reinterpret_cast<bf16x8*>(&bu), acc, 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
       float av[4], bv[4];
@@ -607,11 +655,15 @@ bool fast_ok(const GemmArgs& a) {
   return ok;
 }
 
+int g_matmul_bf16 = 0;  // tatt_set_matmul_precision
+
 template <int AOP, int BOP>
 int launch(const GemmArgs& a, int batch, hipStream_t st) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch * a.splitk);
-  if (fast_ok<AOP, BOP>(a)) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true>), grid, dim3(NTHR), 0, st, a);
-  else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, false>), grid, dim3(NTHR), 0, st, a);
+  if (fast_ok<AOP, BOP>(a)) {
+    if (g_matmul_bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true>), grid, dim3(NTHR), 0, st, a);
+    else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true>), grid, dim3(NTHR), 0, st, a);
+  } else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, false>), grid, dim3(NTHR), 0, st, a);
   TATT_LAUNCH_CHECK("gemm_kernel");
   return TATT_OK;
 }
@@ -619,6 +671,13 @@ int launch(const GemmArgs& a, int batch, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+int tatt_set_matmul_precision(int mode) {
+  TATT_CHECK_ARG(mode == 0 || mode == 1, "tatt_set_matmul_precision: mode is 0 (fp32) or 1 (bf16 operands, fp32 accumulate)");
+  g_matmul_bf16 = mode;
+  return TATT_OK;
+}
+int tatt_get_matmul_precision(void) { return g_matmul_bf16; }
 
 int tatt_conv_pack_w(const float* Wt, float* Wf, float* Wd, int Cout, int Cin, int KH, int KW, hipStream_t st) {
   TATT_CHECK_ARG(Wt && Wf && Wd && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "tatt_conv_pack_w: bad arguments");

@@ -1,0 +1,126 @@
+"""bf16 matrix-core mode (tatt_set_matmul_precision(1); BASELINE config 3): operands rounded to bf16 (nearest-even), fp32
+accumulate.  Kernel-level: exact in the sense that the result equals the fp64 product of the bf16-ROUNDED operands to fp32
+accumulation accuracy (5e-6 rel-L2).  Model-level: the tolerances SURVEY §8c proposes for bf16 (output max-abs <= 1e-2,
+rel-L2 <= 1e-2, gradient cosine >= 0.999) against the fp64 oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def L():
+    from tatt_amd.lib import lib
+    return lib()
+
+
+@pytest.fixture(autouse=True)
+def bf16_mode():
+    L().set_matmul_precision(1)
+    assert L().get_matmul_precision() == 1
+    yield
+    L().set_matmul_precision(0)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def r16(t):
+    return t.bfloat16().double()
+
+
+def close(got, ref, tol, what):
+    r = rel_l2(got.detach().cpu().double().numpy(), ref.detach().double().numpy())
+    assert r <= tol and torch.isfinite(got).all(), f"{what}: rel-L2 {r:.3e} > {tol}"
+
+
+def ws(n=8 << 20):
+    return torch.empty(n, device="cuda")
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 96, 64), (64, 1536, 512), (4096, 64, 2448), (132, 40, 96), (128, 64, 32)])
+def test_gemm_all_layouts(M, N, K):
+    A, B_, bias = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2)
+    out = torch.empty(M, N, device="cuda")
+    L().gemm(A.cuda(), B_.cuda(), out, bias.cuda(), M, N, K, K, 1, K, 1, N, 1, 0, 0, 0, 0, 0, 1, None)            # NT
+    ref = r16(A) @ r16(B_).t() + bias.double()
+    close(out, ref, 5e-6, "nt (bf16-rounded operands)")
+    assert rel_l2(out.cpu().double().numpy(), (A.double() @ B_.double().t() + bias.double()).numpy()) > 1e-4   # it IS bf16
+    Bt = B_.t().contiguous()                                                                                    # NN: B row-contiguous
+    L().gemm(A.cuda(), Bt.cuda(), out, None, M, N, K, K, 1, 1, N, N, 1, 0, 0, 0, 0, 0, 1, None)
+    close(out, r16(A) @ r16(B_).t(), 5e-6, "nn")
+    At = A.t().contiguous()                                                                                     # TN, split-K
+    L().gemm(At.cuda(), B_.cuda(), out, None, M, N, K, 1, M, K, 1, N, 1, 0, 0, 0, 0, 0, 2, ws())
+    close(out, r16(A) @ r16(B_).t(), 5e-6, "tn split-K")
+    L().gemm(At.cuda(), Bt.cuda(), out, None, M, N, K, 1, M, 1, N, N, 1, 0, 0, 0, 0, 0, 1, None)                # TT
+    close(out, r16(A) @ r16(B_).t(), 5e-6, "tt")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(2, 16, 64, 64, 64, 3), (2, 16, 64, 64, 256, 3), (3, 8, 32, 32, 64, 3), (1, 32, 128, 64, 4, 9)])
+def test_conv_fwd_dgrad_wgrad(B, H, W, Cin, Cout, k):
+    x, dy = rnd(B, Cin, H, W), rnd(B, Cout, H, W, seed=3)
+    w, b = rnd(Cout, Cin, k, k, seed=1) / math.sqrt(Cin * k * k), rnd(Cout, seed=2)
+    xr, wr, dyr = (r16(t).requires_grad_(True) for t in (x, w, dy))
+    y = F.conv2d(xr, wr, b.double(), padding=k // 2)
+    gx, gw = torch.autograd.grad(F.conv2d(xr, wr, None, padding=k // 2), (xr, wr), dyr.detach())
+    xn, dyn = x.permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda()
+    T = k * k
+    wf, wd = torch.empty(w.numel(), device="cuda"), torch.empty(w.numel(), device="cuda")
+    L().conv_pack_w(w.cuda(), wf, wd, Cout, Cin, k, k)
+    out, dx = torch.empty(B, H, W, Cout, device="cuda"), torch.empty(B, H, W, Cin, device="cuda")
+    L().conv_fwd(xn, wf, b.cuda(), out, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, 0, 0)
+    close(out.permute(0, 3, 1, 2), y, 5e-6, "fwd")
+    if Cout % 32 == 0:                                       # the 64 -> 4 convolution's dgrad runs on the skinny kernels (fp32)
+        L().conv_fwd(dyn, wd, None, dx, B, H, W, Cout, Cin, k, k, Cout, Cin, T * Cout, 1, 0, Cout, 0, 0)
+        close(dx.permute(0, 3, 1, 2), gx, 5e-6, "dgrad")
+    dW = torch.zeros(Cout, Cin, k, k, device="cuda")
+    L().conv_wgrad(xn, dyn, dW, B, H, W, Cin, Cout, k, k, Cin, Cout, 4, ws(), 1)
+    close(dW, gw, 5e-6, "wgrad")
+
+
+def test_model_forward_backward_within_bf16_tolerance():
+    """Whole SR network, train mode, B=4: fp64 oracle vs the bf16-operand GPU path (SURVEY §8c bf16 tolerances)."""
+    from oracle import procgen, tatt_ref as R
+    from tests.util import make_state
+    from tatt_amd.model.tsrn import TSRN_TL_TRANS
+    B = 4
+    P = make_state(37)
+    hr, lr, tp = procgen.make_inputs(B, 37, seed=2)
+    P64 = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in P.items()}
+    sr64 = R.tsrn_forward(P64, lr.double(), tp.double(), training=True)
+    loss64 = R.image_loss(sr64, hr.double()).mean() * 100
+    loss64.backward()
+    m = TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32)
+    m.load_state_dict(P, strict=True)
+    m = m.cuda().train()
+    m.dropout_p = 0.0                                         # parity is defined with dropout off
+    sr = m(lr.cuda(), tp.cuda())
+    from tatt_amd.loss.image_loss import ImageLoss
+    loss = ImageLoss(gradient=True, loss_weight=[1, 1e-4])(sr, hr.cuda()).mean() * 100
+    loss.backward()
+    # yardstick: the same oracle under torch's CPU autocast(bfloat16) -- what "bf16 training" of this network means in stock
+    # PyTorch (conv / linear / matmul in bf16 WITH bf16 outputs); the HIP path keeps fp32 outputs and must not be worse
+    P32 = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in P.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        sr_ac = R.tsrn_forward(P32, lr, tp, training=True)
+    (R.image_loss(sr_ac.float(), hr).mean() * 100).backward()
+    d_ac = (sr_ac.detach().double() - sr64.detach()).abs().max().item()
+    r_ac = rel_l2(sr_ac.detach().double().numpy(), sr64.detach().numpy())
+    d = (sr.detach().cpu().double() - sr64.detach()).abs().max().item()
+    r = rel_l2(sr.detach().cpu().double().numpy(), sr64.detach().numpy())
+    names = [n for n, p in m.named_parameters() if p.grad is not None and P64[n].grad is not None]
+    flat = lambda get: torch.cat([get(n).double().reshape(-1) for n in names])
+    g, g64, gac = flat(lambda n: dict(m.named_parameters())[n].grad.detach().cpu()), flat(lambda n: P64[n].grad), flat(lambda n: P32[n].grad)
+    cos = float((g @ g64) / (g.norm() * g64.norm()))
+    cos_ac = float((gac @ g64) / (gac.norm() * g64.norm()))
+    print(f"bf16 HIP: max-abs {d:.3e} rel-L2 {r:.3e} grad cos {cos:.5f} | autocast oracle: {d_ac:.3e} {r_ac:.3e} {cos_ac:.5f}")
+    assert d > 1e-5                                           # it is not the fp32 path
+    assert d <= max(1e-2, d_ac) and r <= max(1e-2, r_ac), (d, r, d_ac, r_ac)
+    assert abs(loss.item() - loss64.item()) <= 2e-2 * abs(loss64.item())
+    assert cos >= min(0.999, cos_ac), (cos, cos_ac)

@@ -1,9 +1,12 @@
 """Timings of the §8(f) kernels around the hot path: input transform, CRNN prior, CTC decode, eval metrics (B=64).
 python tools/bench_aux.py"""
+import os
+import sys
+
 import numpy as np
 import torch
 
-from oracle import procgen
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tatt_amd.dataset import pack_images
 from tatt_amd.lib import lib
 from tatt_amd.model.crnn import CRNN
