@@ -64,18 +64,19 @@ __global__ void sum_partials_k(const float* __restrict__ partial, int n, float s
   out[0] = accumulate ? out[0] + s : s;
 }
 
-// column sums of [R,C] (ld) : stage 1 partial[blk][C]
+// column sums of [R,C] (ld) : stage 1 partial[blk][C]; blockIdx.x = row block, blockIdx.y = chunk of 1024 columns
 __global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict__ x, long ld, int R, int C, int rows_per_blk,
                                                         float* __restrict__ partial) {
   __shared__ float red[256];
   const int tid = threadIdx.x;
   const int rb = blockIdx.x * rows_per_blk, re = min(R, rb + rows_per_blk);
-  if ((C & 3) == 0 && (ld & 3) == 0 && ((((uintptr_t)x) & 15) == 0) && C <= 1024) {
+  const int cbeg = blockIdx.y * 1024, cend = min(C, cbeg + 1024);
+  if ((C & 3) == 0 && (ld & 3) == 0 && ((((uintptr_t)x) & 15) == 0)) {
     // vector path: thread = (float4 column group, row lane); four independent accumulators keep loads in flight
     __shared__ float4 red4[256];
-    const int C4 = C >> 2, CT4 = C4 < 256 ? C4 : 256, RL4 = 256 / CT4;
+    const int C4 = (cend - cbeg) >> 2, CT4 = C4, RL4 = 256 / CT4;
     const int cl4 = tid % CT4, rl4 = tid / CT4;
-    for (int c4 = cl4; c4 < C4; c4 += CT4) {
+    for (int c4 = (cbeg >> 2) + cl4; c4 < (cend >> 2); c4 += CT4) {
       float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
       if (rl4 < RL4) {
         int r = rb + rl4;
@@ -117,9 +118,9 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict_
     }
     return;
   }
-  const int CT = C < 256 ? C : 256, RL = 256 / CT;
+  const int CT = cend - cbeg < 256 ? cend - cbeg : 256, RL = 256 / CT;
   const int cl = tid % CT, rl = tid / CT;
-  for (int c = cl; c < C; c += CT) {
+  for (int c = cbeg + cl; c < cend; c += CT) {
     float s = 0.f;
     if (rl < RL)
       for (int r = rb + rl; r < re; r += RL) s += x[(long)r * ld + c];
@@ -315,10 +316,15 @@ int tatt_prelu_bwd(const float* x, const float* slope, const float* dy, float* d
 size_t tatt_colsum_workspace(int C) { return (size_t)256 * C; }
 int tatt_colsum(const float* x, long ld, int R, int C, float* out, int accumulate, float* workspace, hipStream_t st) {
   TATT_CHECK_ARG(R > 0 && C > 0 && (C > 256 || 256 % C == 0 || true), "tatt_colsum: bad dims");
-  int rpb = R >= 64 * 256 ? cdiv(R, 256) : 64;  // up to 256 blocks, four 16-byte loads in flight per thread (more blocks measured slower)
-  int nblk = cdiv(R, rpb);
-  // CT = min(C,256) must divide 256 for the row-lane split; otherwise fall back to one row lane
-  hipLaunchKernelGGL(colsum_partial_k, dim3(nblk), dim3(256), 0, st, x, ld, R, C, rpb, workspace);
+  // up to 256 row blocks (more measured slower on [65536,64]) x chunks of 1024 columns, ~512 workgroups in all: wide matrices
+  // (the RPE gate gradients are [4096,3072]) would otherwise leave a few blocks walking thousands of columns
+  const int ncy = cdiv(C, 1024);
+  int nbr = cdiv(512, ncy);
+  if (nbr > 256) nbr = 256;
+  if (nbr > cdiv(R, 16)) nbr = cdiv(R, 16);
+  const int rpb = cdiv(R, nbr);
+  const int nblk = cdiv(R, rpb);
+  hipLaunchKernelGGL(colsum_partial_k, dim3(nblk, ncy), dim3(256), 0, st, x, ld, R, C, rpb, workspace);
   TATT_LAUNCH_CHECK("colsum_partial");
   hipLaunchKernelGGL(colsum_final_k, dim3(cdiv(C, 16)), dim3(256), 0, st, workspace, nblk, C, out, accumulate);
   TATT_LAUNCH_CHECK("colsum_final");

@@ -11,6 +11,7 @@
 namespace {
 
 constexpr int TN_WAVES = 8, TN_MAXBLK = 256;
+constexpr int OOB = (int)0x80000000;  // buffer offset beyond num_records: the load returns 0
 
 template <int MT, int NT>
 __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx,
@@ -39,18 +40,34 @@ __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_kernel(const float* __
 #pragma unroll
   for (int b = 0; b < NT; ++b) nok[b] = b * 32 + li < N;
 
-  constexpr int U = (MT * NT >= 6) ? 4 : 8;  // k-pairs in flight (bounded by the VGPR budget of the 3x2 variant)
-  for (int r = r0; r < r1; r += 2 * U) {
-    float av[U][MT], bv[U][NT];
+  // Two register sets of U k-pairs each: the loads of the next set are issued before the MFMAs of the current one, so the
+  // HBM latency and the matrix work (0.8 GFLOP for a [96,64] output, as long as the 42 MB stream itself) overlap inside a
+  // wave instead of adding up.  Straight-line, two sets per trip, rows past r1 predicated to zero.
+  constexpr int U = 4;
+  float av0[U][MT], bv0[U][NT], av1[U][MT], bv1[U][NT];
+  // Branch-free predication (a branch per load serialises them and forces vmcnt(0) before the first MFMA): raw buffer loads
+  // whose per-lane offset is swapped for an out-of-range one when the row or column is off -- the descriptor returns 0.
+  // Per-lane offsets are constants (column + lane half's row), the row position is the wave-uniform soffset.
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, OOB, 0x00020000);
+  int cy[MT], cx[NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) cy[a] = mok[a] ? (int)((lh * lddy + a * 32 + li) * 4) : OOB;
+#pragma unroll
+  for (int b = 0; b < NT; ++b) cx[b] = nok[b] ? (int)((lh * ldx + b * 32 + li) * 4) : OOB;
+  const int sy = (int)lddy * 4, sx = (int)ldx * 4;
+  auto load = [&](int r, float (&av)[U][MT], float (&bv)[U][NT]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int row = r + 2 * u + lh;
-      const bool rok = row < r1;
+      const int rw = r + 2 * u;
+      const bool rok = rw + lh < r1;
 #pragma unroll
-      for (int a = 0; a < MT; ++a) av[u][a] = (rok && mok[a]) ? dY[(long)row * lddy + a * 32 + li] : 0.f;
+      for (int a = 0; a < MT; ++a) av[u][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rY, rok ? cy[a] : OOB, rw * sy, 0));
 #pragma unroll
-      for (int b = 0; b < NT; ++b) bv[u][b] = (rok && nok[b]) ? X[(long)row * ldx + b * 32 + li] : 0.f;
+      for (int b = 0; b < NT; ++b) bv[u][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, rok ? cx[b] : OOB, rw * sx, 0));
     }
+  };
+  auto mma = [&](const float (&av)[U][MT], const float (&bv)[U][NT]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -60,6 +77,13 @@ __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_kernel(const float* __
         for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
       }
     }
+  };
+  load(r0, av0, bv0);
+  for (int r = r0; r < r1; r += 4 * U) {
+    load(r + 2 * U, av1, bv1);
+    mma(av0, bv0);
+    load(r + 4 * U, av0, bv0);
+    mma(av1, bv1);
   }
   // ---- tree-sum the eight waves through LDS: waves [h, 2h) park their partial in slot (wave - h), waves [0, h) add it ----
   constexpr int NW = NT * 32;
@@ -135,6 +159,8 @@ size_t tatt_tn_small_workspace(int M, int N) { return (size_t)TN_MAXBLK * ((size
 int tatt_tn_small(const float* dY, long lddy, const float* X, long ldx, float* dW, long lddw, float* db, int M, int N, int R,
                   float* workspace, hipStream_t st) {
   TATT_CHECK_ARG(M > 0 && N > 0 && R > 0 && M <= 96 && N <= 64 && workspace, "tatt_tn_small: need 0 < M <= 96, 0 < N <= 64 (got %d, %d)", M, N);
+  TATT_CHECK_ARG(((long)R + 1) * lddy * 4 < (1L << 31) && ((long)R + 1) * ldx * 4 < (1L << 31) && lddy > 0 && ldx > 0,
+                 "tatt_tn_small: operands must span less than 2 GiB (32-bit buffer offsets)");
   int nblk = (R + 255) / 256;
   if (nblk > TN_MAXBLK) nblk = TN_MAXBLK;  // one 8-wave block per CU: enough loads in flight to stream near the HBM rate
   int rpb = ((R + nblk - 1) / nblk + 15) / 16 * 16;

@@ -7,6 +7,8 @@ views of the same buffers.  Reference call stack: SURVEY.md §3.2 (model/tsrn.py
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .lib import lib
@@ -49,6 +51,16 @@ class Engine:
         self.seed_dev = None      # optional uint32 device tensor added to the dropout seed (graph-captured training)
         self.wpack = {}
         self._side = None         # side stream of the RPE recurrence (see forward)
+        # Weight-gradient kernels are leaves of the backward pass: nothing downstream reads dW before the optimiser.  In "batch"
+        # mode they are collected and issued in groups on their own stream (a parallel branch of the captured hipGraph), so that
+        # their ramp-up and under-filled tails overlap with the dgrad chain; see _wgrad().  "off" = in line on the main stream.
+        # Measured at B=64 (ms/step): off 12.82, one fork per kernel 12.92 (each cross-stream dependency costs more than it
+        # hides), one fork per half SRB 12.23.  Upper bound if the 3.8 ms of weight-gradient kernels were free: 8.99.
+        self.wgrad_mode = os.environ.get("TATT_WGRAD_STREAM", "batch")
+        if self.wgrad_mode not in ("batch", "off"):
+            raise RuntimeError("TATT_WGRAD_STREAM must be 'batch' or 'off'")
+        self._wside, self.ws_w = None, None
+        self._w_keep, self._w_pending, self._w_defer = [], set(), []
 
     # ---- parameters --------------------------------------------------------------------------------
     def param_list(self):
@@ -81,6 +93,46 @@ class Engine:
             self._side = torch.cuda.Stream(device=self.dev)
         return self._side
 
+    # ---- weight-gradient stream ------------------------------------------------------------------------------
+    def _wgrad(self, fn, dys, xs=()):
+        """Queue fn(workspace) -- weight-gradient kernels reading the tensors `dys` (gradients) and `xs` (saved activations) --
+        for the weight-gradient stream; _w_flush() launches the queue there, ordered after everything the main stream has
+        issued by then.  The operands are kept alive until the next join (the caching allocator must not hand their memory
+        to a later main-stream tensor), and the gradients are remembered by storage so that _guard() can order a later
+        in-place update of one of them after the queued reads."""
+        if self.wgrad_mode != "batch":
+            return fn(self.ws)
+        self._w_defer.append(fn)                              # launched on the weight-gradient stream at the next _w_flush()
+        self._w_keep.extend(dys)
+        self._w_keep.extend(xs)
+        self._w_pending.update(t.untyped_storage().data_ptr() for t in dys)
+
+    def _w_flush(self):
+        """One fork for everything queued so far (a cross-stream dependency per kernel costs more than it hides)."""
+        if not self._w_defer:
+            return
+        main = torch.cuda.current_stream()
+        if self._wside is None or self._wside.device != self.dev:
+            self._wside = torch.cuda.Stream(device=self.dev)
+            self.ws_w = torch.empty(WS_FLOATS, device=self.dev, dtype=torch.float32)
+        self._wside.wait_stream(main)
+        with torch.cuda.stream(self._wside):
+            for fn in self._w_defer:
+                fn(self.ws_w)
+        self._w_defer = []
+
+    def _w_join(self):
+        """Main stream waits for the weight-gradient stream (before a bucket's all-reduce, the optimiser, or a guarded write)."""
+        self._w_flush()
+        if self._wside is not None and (self._w_keep or self._w_pending):
+            torch.cuda.current_stream().wait_stream(self._wside)
+            self._w_keep, self._w_pending, self._w_defer = [], set(), []
+
+    def _guard(self, t):
+        """Call before the main stream writes `t` in place: if a pending weight-gradient kernel still reads it, join first."""
+        if self._w_pending and t is not None and t.untyped_storage().data_ptr() in self._w_pending:
+            self._w_join()
+
     def new(self, *shape):
         return torch.empty(shape, device=self.dev, dtype=torch.float32)
 
@@ -102,26 +154,27 @@ class Engine:
 
     def linear_dx(self, dy, W, dx, R, N, K, lddy=None, ldw=None, lddx=None, acc=0, splitk=1):
         """dx[R,K] (+)= dy[R,N] @ W[N,K]"""
+        self._guard(dx)
         self.L.gemm(dy, W, dx, None, R, K, N, lddy or N, 1, 1, ldw or K, lddx or K, 1, 0, 0, 0, acc, 0, splitk,
                     self.ws if splitk > 1 else None)
 
     def linear_dw(self, dy, x, dW, R, N, K, lddy=None, ldx=None, lddw=None):
         """dW[N,K] += dy[R,N]^T @ x[R,K]  (always accumulates into the gradient buffer)"""
         sk = self._splitk(N, K, R)
-        self.L.gemm(dy, x, dW, None, N, K, R, 1, lddy or N, 1, ldx or K, lddw or K, 1, 0, 0, 0, 1, 0, sk,
-                    self.ws if sk > 1 else None)
+        self._wgrad(lambda ws: self.L.gemm(dy, x, dW, None, N, K, R, 1, lddy or N, 1, ldx or K, lddw or K, 1, 0, 0, 0, 1, 0, sk,
+                                           ws if sk > 1 else None), [dy], [x])
 
     def linear_dwb(self, dy, x, dW, db, R, N, K, lddy=None, ldx=None, lddw=None):
         """dW[N,K] += dy^T x and db[N] += colsum(dy): one streaming pass (tatt_tn_small) when the output is small."""
         if N <= 96 and K <= 64:
-            self.L.tn_small(dy, lddy or N, x, ldx or K, dW, lddw or K, db, N, K, R, self.ws)
+            self._wgrad(lambda ws: self.L.tn_small(dy, lddy or N, x, ldx or K, dW, lddw or K, db, N, K, R, ws), [dy], [x])
             return
         self.linear_dw(dy, x, dW, R, N, K, lddy=lddy, ldx=ldx, lddw=lddw)
         if db is not None:
             self.colsum(dy, R, N, db, ld=lddy)
 
     def colsum(self, x, R, C, out, ld=None):
-        self.L.colsum(x, ld or C, R, C, out, 1, self.ws)
+        self._wgrad(lambda ws: self.L.colsum(x, ld or C, R, C, out, 1, ws), [x])
 
     def _skinny(self, x, W, b, out, B, H, Wd, Cin, Cout, k, wstr, acc):
         wsz = self.L.conv_skinny_workspace(B, H, Wd, Cin, Cout, k, k)
@@ -159,6 +212,7 @@ class Engine:
     def conv_dgrad(self, dy, W, dx, B, H, Wd, Cin, Cout, k, acc=0):
         """dx[B,H,W,Cin] (+)= conv^T(dy[B,H,W,Cout]);  W is the forward OIHW weight [Cout,Cin,k,k]."""
         T = k * k
+        self._guard(dx)
         if Cin in (4, 8, 16):
             return self._skinny(dy, W, None, dx, B, H, Wd, Cout, Cin, k, (T, Cin * T, T - 1, -1), acc)
         self.L.conv_fwd_splitk(dy, self._packed(W, Cout, Cin, k)[1], None, dx, B, H, Wd, Cout, Cin, k, k, Cout, Cin,
@@ -175,7 +229,7 @@ class Engine:
         sk = max(1, min((B * H * Wd) // 256, -(-1024 // tiles)))
         while sk > 1 and Cout * T * Cin * sk > WS_FLOATS:
             sk //= 2
-        self.L.conv_wgrad(x, dy, dW, B, H, Wd, Cin, Cout, k, k, Cin, Cout, sk, self.ws, 1)
+        self._wgrad(lambda ws: self.L.conv_wgrad(x, dy, dW, B, H, Wd, Cin, Cout, k, k, Cin, Cout, sk, ws, 1), [dy], [x])
         self.colsum(dy, B * H * Wd, Cout, db)
 
     def bn(self, pre, x, R, C, train, act, out=None, res=None):
@@ -299,6 +353,7 @@ class Engine:
         self.linear_dwb(df, hd, G[pre + "linear2.weight"], G[pre + "linear2.bias"], R, 64, 64)
         dh = self.new(R, 64)
         self.linear_dx(df, P[pre + "linear2.weight"], dh, R, 64, 64)
+        self._guard(dh)
         self.L.relu_drop_bwd(h, dh, dh, R * 64, *cfg)
         self.linear_dwb(dh, x, G[pre + "linear1.weight"], G[pre + "linear1.bias"], R, 64, 64)
         self.linear_dx(dh, P[pre + "linear1.weight"], dx, R, 64, 64, acc=1)
@@ -312,6 +367,7 @@ class Engine:
     def ln_bwd(self, pre, v, dy, dyscale, dv, dv_acc, cfg, R, G, want_dres):
         """dv (+)= grad wrt the LN input v;  returns dres (grad wrt the dropped residual branch)."""
         dres = self.new(R, 64) if (want_dres and cfg[1]) else None
+        self._guard(dv)
         self.L.ln_bwd(v, dy, dyscale, self.P[pre + "weight"], dv, dv_acc, dres, *cfg, G[pre + "weight"], G[pre + "bias"], 1, R,
                       1e-5, self.ws)
         return dres
@@ -494,7 +550,20 @@ class Engine:
         """Accumulates parameter gradients of one forward call into G (dict name -> fp32 tensor).
         on_stage(name) is called when a gradient bucket is complete ("tail", "srbs", "head", "infogen" -- the RPE chain finishes last):
         the data-parallel trainer starts that bucket's all-reduce there, overlapping the rest of the pass."""
-        on_stage = on_stage or (lambda name: None)
+        user_stage = on_stage
+
+        def on_stage(name):                                   # a bucket is complete only once its weight gradients have landed
+            if user_stage is not None:
+                self._w_join()
+                user_stage(name)
+            elif name == "infogen":                           # end of the pass: the optimiser reads every gradient
+                self._w_join()
+            else:
+                self._w_flush()
+
+        def axpby(x, a, y, b, out, n, accumulate):            # every in-place update of a gradient tensor goes through the guard
+            self._guard(out)
+            L.axpby(x, a, y, b, out, n, accumulate)
         L, m, P = self.L, self.m, self.P
         B, training, seed, p = ctx["meta"]
         self.wpack = ctx["wpack"]
@@ -535,6 +604,7 @@ class Engine:
             self.gru_block_bwd(pre + "gru1.", ds, [(r2, 0, 64, dr2, 0), (tp_map, 64, 64, dtp, 0 if first_tp else 1)], B, H, W,
                                True, ctx, pre + "gru1", G)
             first_tp = False
+            self._w_flush()
             dcb = self.bn_bwd(pre + "bn2.", cb, dr2, st2, R0, 64, 0, training, G)
             self.conv_wgrad(ma, dcb, G[pre + "conv2.weight"], G[pre + "conv2.bias"], B, H, W, 64, 64, 3)
             dma = self.new(R0, 64)
@@ -543,7 +613,8 @@ class Engine:
             self.conv_wgrad(blk, dca, G[pre + "conv1.weight"], G[pre + "conv1.bias"], B, H, W, 64, 64, 3)
             self.conv_dgrad(dca, P[pre + "conv1.weight"], ds, B, H, W, 64, 64, 3, acc=1)     # dx = ds + conv1^T(dca)
             dout = ds
-        L.axpby(dout, 1.0, None, 0.0, db1, R0 * 64, 1)
+            self._w_flush()
+        axpby(dout, 1.0, None, 0.0, db1, R0 * 64, 1)
         on_stage("srbs")
 
         # ---- TP interpreter --------------------------------------------------------------------------------------
@@ -567,11 +638,11 @@ class Engine:
             last = li == 1
             self.mha_bwd(d + "multihead_attn.", da if da is not None else dtgt, att, qin, kin, mem, B, H * W,
                          cfg(f"dec{li}_attn"), G, dqin, dkin, dmem, 0, 0 if last else 1, 0 if last else 1)
-            L.axpby(dqin, 1.0, None, 0.0, dtgt, R0 * 64, 1)
-            L.axpby(dqin, 1.0, None, 0.0, dqp, R0 * 64, 0 if last else 1)
+            axpby(dqin, 1.0, None, 0.0, dtgt, R0 * 64, 1)
+            axpby(dqin, 1.0, None, 0.0, dqp, R0 * 64, 0 if last else 1)
             dnext = dtgt
-        L.axpby(dnext, 1.0, None, 0.0, db1, R0 * 64, 1)
-        L.axpby(dkin, 1.0, None, 0.0, dmem, Rt * 64, 1)                     # kin = mem + pos
+        axpby(dnext, 1.0, None, 0.0, db1, R0 * 64, 1)
+        axpby(dkin, 1.0, None, 0.0, dmem, Rt * 64, 1)                     # kin = mem + pos
         # recurrent positional encoding, BPTT over the batch axis: dqp is complete here.  The chain of B latency-bound
         # launches runs on the side stream beside the encoder / block1 / STN backward; its weight-gradient GEMMs (which
         # need the shared workspace) follow after the join at the end of the pass.
@@ -611,9 +682,9 @@ class Engine:
         dqk = self.new(Rt, 64)
         self.mha_bwd(e + "self_attn.", dae if dae is not None else dsrc2, att_e, qk, qk, src2, B, 26, cfg("enc_attn"), G,
                      dqk, dqk, dsrc2, 0, 1, 1)
-        L.axpby(dqk, 1.0, None, 0.0, dsrc2, Rt * 64, 1)
+        axpby(dqk, 1.0, None, 0.0, dsrc2, Rt * 64, 1)
         dt = self.new(Rt, 64)
-        L.axpby(dsrc2, 2.0, None, 0.0, dt, Rt * 64, 0)
+        axpby(dsrc2, 2.0, None, 0.0, dt, Rt * 64, 0)
         dt0 = self.new(Rt, 64)
         L.prelu_bwd(t0, P[ig + "activation.weight"], dt, dt0, G[ig + "activation.weight"], 1, Rt * 64, self.ws)
         self.linear_dwb(dt0, tpr, G[ig + "fc_in.weight"], G[ig + "fc_in.bias"], Rt, 64, K)
@@ -637,7 +708,7 @@ class Engine:
         self.colsum(dctrl, B, 40, G["stn_head.stn_fc2.bias"])
         dfeat = self.new(B, 512)
         self.linear_dx(dctrl, P["stn_head.stn_fc2.weight"], dfeat, B, 40, 512)
-        L.axpby(dfeat, 0.1, None, 0.0, dfeat, B * 512, 0)
+        axpby(dfeat, 0.1, None, 0.0, dfeat, B * 512, 0)
         dl1 = self.bn_bwd("stn_head.stn_fc1.1.", l1, dfeat, stat1, B, 512, 1, True, G)
         self.linear_dw(dl1, f, G["stn_head.stn_fc1.0.weight"], B, 512, 512)
         self.colsum(dl1, B, 512, G["stn_head.stn_fc1.0.bias"])

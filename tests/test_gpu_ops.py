@@ -394,7 +394,7 @@ def test_elementwise_layout_kernels():
     o_ = cu(torch.ones(1000))
     L().axpby(cu(a_), 2.0, cu(b_), -0.5, o_, 1000, 1)
     close(o_, 1 + 2 * a_ - 0.5 * b_, what="axpby")
-    for R_, C_ in ((3000, 96), (70000, 64), (5, 1536), (9, 40)):
+    for R_, C_ in ((3000, 96), (70000, 64), (5, 1536), (9, 40), (4096, 3072), (64, 3072), (130, 2100), (33, 1027), (1, 4)):
         xc = rnd(R_, C_ + 8)
         oc = torch.zeros(C_, device="cuda")
         L().colsum(cu(xc), C_ + 8, R_, C_, oc, 1, ws())
