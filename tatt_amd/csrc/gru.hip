@@ -49,15 +49,28 @@ __global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, c
   const int T = sm.T;
   long pix = base + (long)(dir ? T - 1 : 0) * sm.tstride;
   const long pstep = dir ? -sm.tstride : sm.tstride;
-  float g_r = gi[pix * 192 + dir * 96 + j], g_z = gi[pix * 192 + dir * 96 + HID + j], g_n = gi[pix * 192 + dir * 96 + 2 * HID + j];
-  for (int t = 0; t < T; ++t) {
-    float nr = 0.f, nz = 0.f, nn = 0.f;
-    if (t + 1 < T) {  // prefetch next step's input projection
-      long np = pix + pstep;
-      nr = gi[np * 192 + dir * 96 + j];
-      nz = gi[np * 192 + dir * 96 + HID + j];
-      nn = gi[np * 192 + dir * 96 + 2 * HID + j];
+  // The horizontal pass has one wave per SIMD, so nothing hides a global load but the chain itself: the input projections
+  // are fetched PF steps ahead, a chunk at a time (time index clamped instead of predicated: no branches around the loads).
+  constexpr int PF = 8;
+  const float* gcol = gi + dir * 96 + j;
+  float c_r[PF], c_z[PF], c_n[PF], q_r[PF], q_z[PF], q_n[PF];
+  auto fetch = [&](int t0, float (&fr)[PF], float (&fz)[PF], float (&fn)[PF]) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int tc = min(t0 + u, T - 1);
+      const float* q = gcol + (base + (long)(dir ? T - 1 - tc : tc) * sm.tstride) * 192;
+      fr[u] = q[0];
+      fz[u] = q[HID];
+      fn[u] = q[2 * HID];
     }
+  };
+  fetch(0, c_r, c_z, c_n);
+  for (int t0 = 0; t0 < T; t0 += PF) {
+    fetch(t0 + PF, q_r, q_z, q_n);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+    if (t0 + u >= T) break;
+    const float g_r = c_r[u], g_z = c_z[u], g_n = c_n[u];
     __builtin_amdgcn_wave_barrier();
     float ar = br, az = bz, an = bn;
 #pragma unroll
@@ -83,7 +96,13 @@ __global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, c
       }
     }
     pix += pstep;
-    g_r = nr; g_z = nz; g_n = nn;
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      c_r[u] = q_r[u];
+      c_z[u] = q_z[u];
+      c_n[u] = q_n[u];
+    }
   }
 }
 
@@ -109,11 +128,32 @@ __global__ __launch_bounds__(256) void gru32_bwd(const float* __restrict__ dout,
   long pix = base + (long)(dir ? 0 : T - 1) * sm.tstride;
   const long pstep = dir ? sm.tstride : -sm.tstride;  // towards the forward-order predecessor
   float dh = 0.f;
-  for (int t = 0; t < T; ++t) {
-    const float* sp = save + (pix * 2 + dir) * 4 * HID;
-    float r = sp[j], z = sp[HID + j], n = sp[2 * HID + j], ghn = sp[3 * HID + j];
-    float hp = (t + 1 < T) ? out[(pix + pstep) * 64 + dir * HID + j] : 0.f;
-    float d = dh + dout[pix * 64 + dir * HID + j];
+  // same scheme as the forward pass: the six per-step operands are fetched PF steps ahead, clamped rather than predicated
+  constexpr int PF = 4;
+  const long pix0 = pix;
+  float c_s[PF][4], c_hp[PF], c_do[PF], q_s[PF][4], q_hp[PF], q_do[PF];
+  auto fetch = [&](int t0, float (&fs)[PF][4], float (&fhp)[PF], float (&fdo)[PF]) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int tc = min(t0 + u, T - 1), tp = min(t0 + u + 1, T - 1);
+      const long pc = pix0 + tc * pstep;
+      const float* sp = save + (pc * 2 + dir) * 4 * HID + j;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fs[u][e] = sp[e * HID];
+      fhp[u] = out[(pix0 + tp * pstep) * 64 + dir * HID + j];
+      fdo[u] = dout[pc * 64 + dir * HID + j];
+    }
+  };
+  fetch(0, c_s, c_hp, c_do);
+  for (int t0 = 0; t0 < T; t0 += PF) {
+    fetch(t0 + PF, q_s, q_hp, q_do);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+    const int t = t0 + u;
+    if (t >= T) break;
+    const float r = c_s[u][0], z = c_s[u][1], n = c_s[u][2], ghn = c_s[u][3];
+    const float hp = (t + 1 < T) ? c_hp[u] : 0.f;
+    float d = dh + c_do[u];
     float dn = d * (1.f - z) * (1.f - n * n);
     float dz = d * (hp - n) * z * (1.f - z);
     float dr = dn * ghn * r * (1.f - r);
@@ -138,6 +178,14 @@ __global__ __launch_bounds__(256) void gru32_bwd(const float* __restrict__ dout,
     }
     dh = acc;
     pix += pstep;
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c_s[u][e] = q_s[u][e];
+      c_hp[u] = q_hp[u];
+      c_do[u] = q_do[u];
+    }
   }
 }
 
