@@ -192,7 +192,12 @@ class SRTrainer:
             self.seed_dev.zero_()
             # the warm-up touched BatchNorm running stats: harmless for a benchmark, noted for training use
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # thread_local: RCCL's watchdog thread polls events of earlier collectives (the parameter broadcast, the previous
+            # step's all-reduce); under the default global mode such a poll from ANOTHER thread during capture aborts the
+            # process (seen once in tests/test_gpu_dp.py when the capture began right after an eager data-parallel step)
+            if self.dp:
+                torch.cuda.synchronize()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.per, _ = self._fwd_bwd(*self.static[:3], overlap=False, arc=self.static[3] if self.tsc else None)
                 if not self.dp:
                     self._update()
@@ -252,7 +257,15 @@ class TATTTrainer(SRTrainer):
         """`tp` is ignored: the prior comes from the student CRNN."""
         L, B = self.L, lr_img.shape[0]
         K = self.student.nclass
-        with torch.no_grad():
+        # Three independent strands: teacher prior (HR image only), the SR step (needs the student's prior), and L_TP with the
+        # student's backward pass (needs both sets of logits, feeds nothing but the student's Adam step).  The teacher and the
+        # L_TP strand run on a second stream -- a parallel branch of the captured graph -- beside the SR step.
+        main = torch.cuda.current_stream()
+        if getattr(self, "_tp_stream", None) is None:
+            self._tp_stream = torch.cuda.Stream(device=lr_img.device)
+        side = self._tp_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
             logits_t = self.teacher.forward_from_images(hr_img)                          # [26, B, K]
         plan = self.student.plan()
         x4 = torch.empty(B, 32, 100, 4, device=lr_img.device)
@@ -262,14 +275,17 @@ class TATTTrainer(SRTrainer):
         probs = torch.empty(T, B, K, device=lr_img.device)
         L.softmax_rows(logits_s, probs, T * B, K)
         prior = probs.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)                 # label_vecs_final: the [B,K,1,26] view
+        # L_TP and the student's backward pass (everything they read was produced above and stays alive until the join)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.s_g.zero_()
+            self.loss_tp = torch.empty(1, device=lr_img.device)
+            dz = torch.empty(T * B, K, device=lr_img.device)
+            ws = torch.empty(L.semantic_loss_workspace(T * B), device=lr_img.device)
+            L.semantic_loss(logits_s, logits_t, self.loss_tp, dz, 100.0, T * B, K, ws)
+            plan.backward(ctx_s, dz.view(T, B, K), self.G_s)
         per, works = super()._fwd_bwd(lr_img, hr_img, prior, overlap, arc=arc)
-        # L_TP and the student's backward pass
-        self.s_g.zero_()
-        self.loss_tp = torch.empty(1, device=lr_img.device)
-        dz = torch.empty(T * B, K, device=lr_img.device)
-        ws = torch.empty(L.semantic_loss_workspace(T * B), device=lr_img.device)
-        L.semantic_loss(logits_s, logits_t, self.loss_tp, dz, 100.0, T * B, K, ws)
-        plan.backward(ctx_s, dz.view(T, B, K), self.G_s)
+        main.wait_stream(side)
         if overlap:
             works.append(allreduce_mean(self.s_g, async_op=True))
         return per, works
