@@ -40,6 +40,10 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
  * db[M] += colsum(dY) in ONE streaming pass over the R rows (autograd of F.linear at the sites above). */
 size_t tatt_tn_small_workspace(int M, int N);
 int tatt_tn_small(const float* dY, long lddy, const float* X, long ldx, float* dW, long lddw, float* db, int M, int N, int R, float* workspace, hipStream_t stream);
+/* Grouped form: nprob <= 8 independent (dY, X, dW, db, M, N, R) problems in ONE launch pair, e.g. the weight gradients of a BiGRU
+ * block (nn.GRU W_ih / W_hh of both directions + the 1x1 conv in front, model/tsrn.py GruBlock).  All array arguments are HOST
+ * arrays of length nprob (db[p] may be NULL); workspace: tatt_tn_small_workspace(96, 64) floats. */
+int tatt_tn_small_group(int nprob, const float* const* dY, const long* lddy, const float* const* X, const long* ldx, float* const* dW, const long* lddw, float* const* db, const int* M, const int* N, const int* R, float* workspace, hipStream_t stream);
 
 /* ---- NHWC implicit-GEMM convolution (stride 1, "same" zero padding), fwd / dgrad / wgrad -------------------
  * Replaces nn.Conv2d at model/tsrn.py:598 (9x9 4->64), :868,:876 (SRB 3x3), :614, :1034 (64->256), :625

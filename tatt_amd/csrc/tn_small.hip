@@ -13,14 +13,13 @@ namespace {
 constexpr int TN_WAVES = 8, TN_MAXBLK = 256;
 constexpr int OOB = (int)0x80000000;  // buffer offset beyond num_records: the load returns 0
 
-template <int MT, int NT>
-__global__ __launch_bounds__(TN_WAVES * 64) void tn_small_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx,
-                                                       int M, int N, int R, int rows_per_blk, float* __restrict__ slabs) {
+template <int MT, int NT, bool SKIP>
+__device__ __forceinline__ void tn_small_body(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx, int M, int N,
+                                              int R, int rows_per_blk, float* __restrict__ slabs, int blk, float* red) {
   constexpr int SLOT = MT * 32 * NT * 32 + MT * 32;  // one wave's partial: the MxN tile + the bias column sums
-  __shared__ float red[(TN_WAVES / 2) * SLOT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int rb = blockIdx.x * rows_per_blk, re = min(R, rb + rows_per_blk);
+  const int rb = blk * rows_per_blk, re = min(R, rb + rows_per_blk);
   const int rows_per_wave = ((rows_per_blk + 2 * TN_WAVES - 1) / (2 * TN_WAVES)) * 2;  // even
   const int r0 = rb + wave * rows_per_wave, r1 = min(re, r0 + rows_per_wave);
   f32x16 acc[MT][NT];
@@ -72,9 +71,11 @@ __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_kernel(const float* __
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int a = 0; a < MT; ++a) {
+        if (SKIP && a * 32 >= M) continue;  // block-uniform: a grouped launch runs smaller problems on the largest tile shape
         asum[a] += av[u][a];
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NT; ++b)
+          if (!SKIP || b * 32 < N) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
       }
     }
   };
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_kernel(const float* __
   }
   // wave 0 holds the block's sum: write the slab straight from its registers
   if (wave == 0) {
-    float* slab = slabs + (long)blockIdx.x * (M * N + M);
+    float* slab = slabs + (long)blk * (M * N + M);
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -130,6 +131,47 @@ __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_kernel(const float* __
         }
       if (lh == 0 && a * 32 + li < M) slab[M * N + a * 32 + li] = asum[a];
     }
+  }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(TN_WAVES * 64) void tn_small_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx,
+                                                       int M, int N, int R, int rows_per_blk, float* __restrict__ slabs) {
+  __shared__ float red[(TN_WAVES / 2) * (MT * 32 * NT * 32 + MT * 32)];
+  tn_small_body<MT, NT, false>(dY, lddy, X, ldx, M, N, R, rows_per_blk, slabs, blockIdx.x, red);
+}
+
+// Grouped form: up to TN_GROUP independent problems in one launch (blockIdx.y = problem), e.g. the four weight gradients of a
+// BiGRU block.  Every problem gets gridDim.x blocks (fewer, longer row ranges and fewer slabs than separate launches).
+constexpr int TN_GROUP = 8;
+struct TnGroup {
+  const float* dY[TN_GROUP];
+  const float* X[TN_GROUP];
+  float* dW[TN_GROUP];
+  float* db[TN_GROUP];
+  long lddy[TN_GROUP], ldx[TN_GROUP], lddw[TN_GROUP], slab_off[TN_GROUP];
+  int M[TN_GROUP], N[TN_GROUP], R[TN_GROUP], rpb[TN_GROUP], nblk[TN_GROUP];
+};
+
+__global__ __launch_bounds__(TN_WAVES * 64) void tn_small_group_kernel(TnGroup g, float* __restrict__ slabs) {
+  __shared__ float red[(TN_WAVES / 2) * (3 * 32 * 2 * 32 + 3 * 32)];
+  const int p = blockIdx.y;
+  if ((int)blockIdx.x >= g.nblk[p]) return;
+  tn_small_body<3, 2, true>(g.dY[p], g.lddy[p], g.X[p], g.ldx[p], g.M[p], g.N[p], g.R[p], g.rpb[p], slabs + g.slab_off[p], blockIdx.x, red);
+}
+
+__global__ void tn_small_group_reduce(TnGroup g, const float* __restrict__ slabs) {
+  __shared__ float red[256];
+  const int p = blockIdx.y, M = g.M[p], N = g.N[p];
+  const int per = M * N + M;
+  if ((int)blockIdx.x * 16 >= per) return;
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+  const float s = block16_colsum(slabs + g.slab_off[p], g.nblk[p], (long)per, i, i < per, red);
+  if (threadIdx.x >= 16 || i >= per) return;
+  if (i < M * N) {
+    g.dW[p][(long)(i / N) * g.lddw[p] + (i % N)] += s;
+  } else if (g.db[p]) {
+    g.db[p][i - M * N] += s;
   }
 }
 
@@ -178,6 +220,43 @@ int tatt_tn_small(const float* dY, long lddy, const float* X, long ldx, float* d
   const int per = M * N + M;
   hipLaunchKernelGGL(tn_small_reduce, dim3(cdiv(per, 16)), dim3(256), 0, st, workspace, nblk, M, N, dW, lddw, db);
   TATT_LAUNCH_CHECK("tn_small_reduce");
+  return TATT_OK;
+}
+
+// Grouped form of tatt_tn_small: nprob <= 8 independent problems (host arrays of length nprob) in one launch pair.
+// workspace: tatt_tn_small_workspace(96, 64) floats cover any group.
+int tatt_tn_small_group(int nprob, const float* const* dY, const long* lddy, const float* const* X, const long* ldx, float* const* dW,
+                        const long* lddw, float* const* db, const int* M, const int* N, const int* R, float* workspace, hipStream_t st) {
+  TATT_CHECK_ARG(nprob > 0 && nprob <= TN_GROUP && dY && lddy && X && ldx && dW && lddw && db && M && N && R && workspace,
+                 "tatt_tn_small_group: need 1..%d problems and non-null arrays", TN_GROUP);
+  TnGroup g;
+  memset(&g, 0, sizeof(g));
+  int nb = TN_MAXBLK / nprob;  // blocks per problem: one 8-wave block per CU in total
+  if (nb < 1) nb = 1;
+  long off = 0;
+  int per_max = 0, nb_max = 0;
+  for (int p = 0; p < nprob; ++p) {
+    TATT_CHECK_ARG(M[p] > 0 && N[p] > 0 && R[p] > 0 && M[p] <= 96 && N[p] <= 64 && dY[p] && X[p] && dW[p],
+                   "tatt_tn_small_group: problem %d: need 0 < M <= 96, 0 < N <= 64, R > 0", p);
+    TATT_CHECK_ARG(lddy[p] > 0 && ldx[p] > 0 && ((long)R[p] + 1) * lddy[p] * 4 < (1L << 31) && ((long)R[p] + 1) * ldx[p] * 4 < (1L << 31),
+                   "tatt_tn_small_group: problem %d: operands must span less than 2 GiB (32-bit buffer offsets)", p);
+    int nblk = (R[p] + 255) / 256;
+    if (nblk > nb) nblk = nb;
+    const int rpb = ((R[p] + nblk - 1) / nblk + 15) / 16 * 16;
+    nblk = (R[p] + rpb - 1) / rpb;
+    g.dY[p] = dY[p]; g.X[p] = X[p]; g.dW[p] = dW[p]; g.db[p] = db[p];
+    g.lddy[p] = lddy[p]; g.ldx[p] = ldx[p]; g.lddw[p] = lddw[p];
+    g.M[p] = M[p]; g.N[p] = N[p]; g.R[p] = R[p]; g.rpb[p] = rpb; g.nblk[p] = nblk;
+    g.slab_off[p] = off;
+    const int per = M[p] * N[p] + M[p];
+    off += (long)nblk * per;
+    if (per > per_max) per_max = per;
+    if (nblk > nb_max) nb_max = nblk;
+  }
+  hipLaunchKernelGGL(tn_small_group_kernel, dim3(nb_max, nprob), dim3(TN_WAVES * 64), 0, st, g, workspace);
+  TATT_LAUNCH_CHECK("tn_small_group_kernel");
+  hipLaunchKernelGGL(tn_small_group_reduce, dim3(cdiv(per_max, 16), nprob), dim3(256), 0, st, g, workspace);
+  TATT_LAUNCH_CHECK("tn_small_group_reduce");
   return TATT_OK;
 }
 

@@ -7,6 +7,7 @@ views of the same buffers.  Reference call stack: SURVEY.md §3.2 (model/tsrn.py
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -173,6 +174,21 @@ class Engine:
         if db is not None:
             self.colsum(dy, R, N, db, ld=lddy)
 
+    def linear_dwb_group(self, probs):
+        """Several linear_dwb problems (dy, x, dW, db, R, N, K, lddy, ldx, lddw) of the small kind (N <= 96, K <= 64) in one
+        launch pair (tatt_tn_small_group): fewer, longer row ranges per workgroup and one slab reduction for the lot."""
+        assert all(p[5] <= 96 and p[6] <= 64 for p in probs)
+        for i in range(0, len(probs), 8):
+            ch = probs[i:i + 8]
+            n = len(ch)
+            VP, LG, IN = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+            args = (n, VP(*[p[0].data_ptr() for p in ch]), LG(*[p[7] or p[5] for p in ch]),
+                    VP(*[p[1].data_ptr() for p in ch]), LG(*[p[8] or p[6] for p in ch]),
+                    VP(*[p[2].data_ptr() for p in ch]), LG(*[p[9] or p[6] for p in ch]),
+                    VP(*[None if p[3] is None else p[3].data_ptr() for p in ch]),
+                    IN(*[p[5] for p in ch]), IN(*[p[6] for p in ch]), IN(*[p[4] for p in ch]))
+            self._wgrad(lambda ws, args=args: self.L.tn_small_group(*args, ws), [p[0] for p in ch], [p[1] for p in ch])
+
     def colsum(self, x, R, C, out, ld=None):
         self._wgrad(lambda ws: self.L.colsum(x, ld or C, R, C, out, 1, ws), [x])
 
@@ -290,15 +306,18 @@ class Engine:
         self.L.gru32_bwd(dout, out, sv, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], dgi, dgh, hprev,
                          *self._seqmap(B, H, W, vertical))
         dg_in = self.new(R, 64)
+        wg = []                                               # all weight gradients of the block: one grouped launch
         for d, sfx in enumerate(["", "_reverse"]):
             gi_d, gh_d, hp_d = dgi.view(-1)[96 * d:], dgh.view(-1)[96 * d:], hprev.view(-1)[32 * d:]
-            self.linear_dwb(gh_d, hp_d, G[pre + "gru.weight_hh_l0" + sfx], G[pre + "gru.bias_hh_l0" + sfx], R, 96, 32, lddy=192, ldx=64)
-            self.linear_dwb(gi_d, g_in, G[pre + "gru.weight_ih_l0" + sfx], G[pre + "gru.bias_ih_l0" + sfx], R, 96, 64, lddy=192)
+            wg.append((gh_d, hp_d, G[pre + "gru.weight_hh_l0" + sfx], G[pre + "gru.bias_hh_l0" + sfx], R, 96, 32, 192, 64, None))
+            wg.append((gi_d, g_in, G[pre + "gru.weight_ih_l0" + sfx], G[pre + "gru.bias_ih_l0" + sfx], R, 96, 64, 192, None, None))
             self.linear_dx(gi_d, P[pre + "gru.weight_ih_l0" + sfx], dg_in, R, 96, 64, lddy=192, acc=d)
         Wc, dWc = P[pre + "conv1.weight"], G[pre + "conv1.weight"]
         Ktot = Wc.shape[1]
         for i, (x, off, kc, dx, acc) in enumerate(inputs):
-            self.linear_dwb(dg_in, x, dWc.view(-1)[off:], G[pre + "conv1.bias"] if i == 0 else None, R, 64, kc, lddw=Ktot)
+            wg.append((dg_in, x, dWc.view(-1)[off:], G[pre + "conv1.bias"] if i == 0 else None, R, 64, kc, None, None, Ktot))
+        self.linear_dwb_group(wg)                             # queued before the input gradients below may update a dx in place
+        for i, (x, off, kc, dx, acc) in enumerate(inputs):
             if dx is not None:
                 self.linear_dx(dg_in, Wc.view(-1)[off:], dx, R, 64, kc, ldw=Ktot, acc=acc)
 
@@ -329,8 +348,9 @@ class Engine:
         self.linear_dx(da, P[pre + "out_proj.weight"], dc, Rq, 64, 64)
         dQ, dK, dV = self.new(Rq, 64), self.new(Rk, 64), self.new(Rk, 64)
         self.L.attn_bwd(Q, K, V, dc, dQ, dK, dV, B, Lq, 26, *cfg, 0)
-        for i, (d, x, R, dx, acc) in enumerate([(dQ, q_in, Rq, dq_in, acc_q), (dK, k_in, Rk, dk_in, acc_k), (dV, v_in, Rk, dv_in, acc_v)]):
-            self.linear_dwb(d, x, dW[64 * i:], db[64 * i:], R, 64, 64)
+        trip = [(dQ, q_in, Rq, dq_in, acc_q), (dK, k_in, Rk, dk_in, acc_k), (dV, v_in, Rk, dv_in, acc_v)]
+        self.linear_dwb_group([(d, x, dW[64 * i:], db[64 * i:], R, 64, 64, None, None, None) for i, (d, x, R, _, _) in enumerate(trip)])
+        for i, (d, x, R, dx, acc) in enumerate(trip):
             if dx is not None:
                 self.linear_dx(d, W[64 * i:], dx, R, 64, 64, acc=acc)
 
