@@ -174,7 +174,7 @@ def main():
                                    "BASELINE config 2: TSRN_TL_TRANS(STN, K=%d) single training step %s, pixel+gradient loss, "
                                    "clip 0.25 + Adam, frozen text prior" % (a.K, prec),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "lr_shape": [4, 16, 64], "hr_shape": [4, 32, 128],
-                       "parallelism": f"dp{world}", "hip_graph": not a.no_graph, "loss": round(loss, 4),
+                       "parallelism": f"dp{world}", "hip_graph": bool(trainer.use_graph), "loss": round(loss, 4),
                        **({"precision": "bf16 MFMA operands (round-to-nearest-even), fp32 accumulate; tensors in HBM, recurrences, "
                                         "norms, losses and optimiser fp32"} if a.bf16 else {})},
             "model_tflops": round(value * FLOP_PER_IMAGE_TRAIN * (2 if a.tsc else 1) / 1e12, 2),

@@ -197,10 +197,18 @@ class SRTrainer:
             # process (seen once in tests/test_gpu_dp.py when the capture began right after an eager data-parallel step)
             if self.dp:
                 torch.cuda.synchronize()
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.per, _ = self._fwd_bwd(*self.static[:3], overlap=False, arc=self.static[3] if self.tsc else None)
-                if not self.dp:
-                    self._update()
+            try:
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self.per, _ = self._fwd_bwd(*self.static[:3], overlap=False, arc=self.static[3] if self.tsc else None)
+                    if not self.dp:
+                        self._update()
+            except Exception as e:                            # keep training: same step, launched eagerly (and say so loudly)
+                import sys
+                print(f"tatt_amd: hipGraph capture of the training step failed ({type(e).__name__}: {e}); continuing with eager "
+                      "launches", file=sys.stderr, flush=True)
+                self.use_graph, self.graph = False, None
+                torch.cuda.synchronize()
+                return self.step(lr_img, hr_img, tp, arc=arc)
         for dst, src in zip(self.static, (lr_img, hr_img, tp) + ((arc,) if self.tsc else ())):
             dst.copy_(src)
         self.graph.replay()
