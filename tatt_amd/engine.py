@@ -48,7 +48,7 @@ class Engine:
         self._names = [n for n, _ in module.named_parameters()]
         self._ptrs = None
         self.P = {}
-        self.debug = None         # set to a dict to stash intermediate gradients (tools/debug_grads.py)
+        self.debug = None         # set to a dict to stash intermediate gradients (tests/debug_grads.py)
         self.seed_dev = None      # optional uint32 device tensor added to the dropout seed (graph-captured training)
         self.wpack = {}
         self._side = None         # side stream of the RPE recurrence (see forward)

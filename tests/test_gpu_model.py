@@ -90,7 +90,7 @@ def test_train_fwd_bwd_vs_oracle_with_stages(p):
     hr, lr, tp = procgen.make_inputs(B, K, seed=2)
     sr, ctx = m.engine().forward(lr.cuda(), tp.cuda(), True, seed, p_drop=p)
     # the oracle runs in fp64 here: it is then the rounding-free statement of the reference algorithm (an fp32 CPU
-    # run of the same code is itself ~8e-3 off on the STN gradients, measured with tools/debug_grads.py)
+    # run of the same code is itself ~8e-3 off on the STN gradients, measured with tests/debug_grads.py)
     P = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in leafify(state).items()}
     P = {k: (v.detach().requires_grad_(True) if v.is_floating_point() and not is_buffer(k) else v) for k, v in P.items()}
     lr, hr, tp = lr.double(), hr.double(), tp.double()
@@ -113,7 +113,7 @@ def test_train_fwd_bwd_vs_oracle_with_stages(p):
     # The same oracle in fp32 measures how far fp32 arithmetic itself lands from the fp64 statement on THIS input: a
     # ReLU / max-pool / bilinear-cell decision of the STN head that sits on a knife edge flips for every fp32
     # implementation alike (seen at B=4: GPU and fp32 CPU both 9.4e-3 from fp64 on stn_convnet.2, 1e-7 from each other
-    # stage by stage, tools/debug_grads.py).  The kernels are held to 3e-3, or to the fp32 oracle's own distance.
+    # stage by stage, tests/debug_grads.py).  The kernels are held to 3e-3, or to the fp32 oracle's own distance.
     P32 = {k: (v.detach().float().requires_grad_(True) if v.is_floating_point() and not is_buffer(k) else
                (v.float() if v.is_floating_point() else v.clone())) for k, v in leafify(state).items()}
     sr32 = R.tsrn_forward(P32, lr.float(), tp.float(), training=True, drop=R.HashDropout(p, seed) if p > 0 else None)
