@@ -4,6 +4,11 @@
 namespace {
 
 constexpr int BN_MAXBLK = 256;
+constexpr int BN_RPT = 8;  // rows per thread of the apply kernels
+inline int bn_apply_grid(int R, int C) {
+  const int c4 = C / 4, CT = c4 < 256 ? c4 : 256, RL = 256 / CT;
+  return cdiv(R, RL * BN_RPT);
+}
 
 // ---- BatchNorm statistics: per-block (mean, M2) over a row range, merged with Chan's formula -------------
 // partial layout: [nblk][2][C]
@@ -140,24 +145,49 @@ __global__ void bn_stat_from_running(const float* __restrict__ rm, const float* 
 __global__ void bn_apply_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ stat,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res,
                                 long ldr, float* __restrict__ y, long ldy, int R, int C, int act) {
-  const int c4 = C >> 2;
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)R * c4) return;
-  int r = (int)(i / c4), c = (int)(i - (long)r * c4) * 4;
-  float4 v = *reinterpret_cast<const float4*>(x + (long)r * ldx + c);
-  float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+  // thread = (float4 channel group, row lane); the channel group's scale/shift is folded once and kept in registers while the
+  // thread walks BN_RPT rows (one thread per float4 re-read 16 parameters for every 16 bytes of payload)
+  const int c4 = C >> 2, CT = c4 < 256 ? c4 : 256, RL = 256 / CT;
+  const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+  if (rl >= RL) return;
+  const int rbase = blockIdx.x * (RL * BN_RPT) + rl;
+  for (int cg = cl; cg < c4; cg += CT) {
+    const int c = cg * 4;
+    float sc[4], sh[4], mu[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float t = (in[e] - stat[c + e]) * stat[C + c + e] * gamma[c + e] + beta[c + e];
-    if (act == 1) t = fmaxf(t, 0.f);
-    else if (act == 2) t = mishf_(t);
-    out[e] = t;
+    for (int e = 0; e < 4; ++e) {
+      mu[e] = stat[c + e];
+      sc[e] = stat[C + c + e];
+      sh[e] = beta[c + e];
+    }
+    float ga[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ga[e] = gamma[c + e];
+    float4 v[BN_RPT];
+#pragma unroll
+    for (int k = 0; k < BN_RPT; ++k) {
+      const int r = rbase + k * RL;
+      if (r < R) v[k] = *reinterpret_cast<const float4*>(x + (long)r * ldx + c);
+    }
+#pragma unroll
+    for (int k = 0; k < BN_RPT; ++k) {
+      const int r = rbase + k * RL;
+      if (r >= R) break;
+      float in[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, out[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = (in[e] - mu[e]) * sc[e] * ga[e] + sh[e];
+        if (act == 1) t = fmaxf(t, 0.f);
+        else if (act == 2) t = mishf_(t);
+        out[e] = t;
+      }
+      if (res) {
+        float4 rr = *reinterpret_cast<const float4*>(res + (long)r * ldr + c);
+        out[0] += rr.x; out[1] += rr.y; out[2] += rr.z; out[3] += rr.w;
+      }
+      *reinterpret_cast<float4*>(y + (long)r * ldy + c) = make_float4(out[0], out[1], out[2], out[3]);
+    }
   }
-  if (res) {
-    float4 rr = *reinterpret_cast<const float4*>(res + (long)r * ldr + c);
-    out[0] += rr.x; out[1] += rr.y; out[2] += rr.z; out[3] += rr.w;
-  }
-  *reinterpret_cast<float4*>(y + (long)r * ldy + c) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
 __device__ __forceinline__ float act_grad(float t, int act) {
@@ -264,28 +294,48 @@ __global__ void bn_bwd_apply(const float* __restrict__ x, long ldx, const float*
                              const float* __restrict__ stat, const float* __restrict__ gamma, const float* __restrict__ beta,
                              const float* __restrict__ sums, float* __restrict__ dx, long lddx, int R, int C, int act, int train,
                              int accumulate) {
-  const int c4 = C >> 2;
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)R * c4) return;
-  int r = (int)(i / c4), c = (int)(i - (long)r * c4) * 4;
-  float4 xv = *reinterpret_cast<const float4*>(x + (long)r * ldx + c);
-  float4 gv = *reinterpret_cast<const float4*>(dy + (long)r * lddy + c);
-  float xi[4] = {xv.x, xv.y, xv.z, xv.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w}, o[4];
+  const int c4 = C >> 2, CT = c4 < 256 ? c4 : 256, RL = 256 / CT;
+  const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+  if (rl >= RL) return;
+  const int rbase = blockIdx.x * (RL * BN_RPT) + rl;
   const float invR = 1.f / (float)R;
+  for (int cg = cl; cg < c4; cg += CT) {
+    const int c = cg * 4;
+    float mean[4], inv[4], ga[4], be[4], s1[4], s2[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float mean = stat[c + e], inv = stat[C + c + e], ga = gamma[c + e];
-    float xh = (xi[e] - mean) * inv;
-    float g = gi[e] * act_grad(xh * ga + beta[c + e], act);
-    float t = train ? (g - sums[c + e] * invR - xh * sums[C + c + e] * invR) : g;
-    o[e] = ga * inv * t;
+    for (int e = 0; e < 4; ++e) {
+      mean[e] = stat[c + e]; inv[e] = stat[C + c + e]; ga[e] = gamma[c + e]; be[e] = beta[c + e];
+      s1[e] = sums[c + e] * invR; s2[e] = sums[C + c + e] * invR;
+    }
+    float4 xv[BN_RPT], gv[BN_RPT];
+#pragma unroll
+    for (int k = 0; k < BN_RPT; ++k) {
+      const int r = rbase + k * RL;
+      if (r < R) {
+        xv[k] = *reinterpret_cast<const float4*>(x + (long)r * ldx + c);
+        gv[k] = *reinterpret_cast<const float4*>(dy + (long)r * lddy + c);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < BN_RPT; ++k) {
+      const int r = rbase + k * RL;
+      if (r >= R) break;
+      float xi[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w}, gi[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w}, o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xh = (xi[e] - mean[e]) * inv[e];
+        float g = gi[e] * act_grad(xh * ga[e] + be[e], act);
+        float t = train ? (g - s1[e] - xh * s2[e]) : g;
+        o[e] = ga[e] * inv[e] * t;
+      }
+      float* d = dx + (long)r * lddx + c;
+      if (accumulate) {
+        float4 p = *reinterpret_cast<const float4*>(d);
+        o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w;
+      }
+      *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
-  float* d = dx + (long)r * lddx + c;
-  if (accumulate) {
-    float4 p = *reinterpret_cast<const float4*>(d);
-    o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w;
-  }
-  *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // ---- LayerNorm over 64 channels: one wave per row, lane = channel ------------------------------------------
@@ -396,8 +446,7 @@ int tatt_bn_stat_from_running(const float* rm, const float* rv, int C, float eps
 int tatt_bn_apply(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr,
                   float* y, long ldy, int R, int C, int act, hipStream_t st) {
   TATT_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "tatt_bn_apply: C/ld must be multiples of 4");
-  long tot = (long)R * (C / 4);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, x, ldx, stat, gamma, beta, res, ldr, y, ldy, R, C, act);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, stat, gamma, beta, res, ldr, y, ldy, R, C, act);
   TATT_LAUNCH_CHECK("bn_apply");
   return TATT_OK;
 }
@@ -414,8 +463,7 @@ int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const floa
   TATT_LAUNCH_CHECK("bn_bwd_reduce");
   hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 16)), dim3(256), 0, st, workspace, nblk, C, sums, dgamma, dbeta, accumulate_params);
   TATT_LAUNCH_CHECK("bn_bwd_final");
-  long tot = (long)R * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_apply, dim3(cdiv(tot, 256)), dim3(256), 0, st, x, ldx, dy, lddy, stat, gamma, beta, sums, dx, lddx, R, C,
+  hipLaunchKernelGGL(bn_bwd_apply, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, dy, lddy, stat, gamma, beta, sums, dx, lddx, R, C,
                      act, train, accumulate_dx);
   TATT_LAUNCH_CHECK("bn_bwd_apply");
   return TATT_OK;
