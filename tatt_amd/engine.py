@@ -571,6 +571,7 @@ class Engine:
         on_stage(name) is called when a gradient bucket is complete ("tail", "srbs", "head", "infogen" -- the RPE chain finishes last):
         the data-parallel trainer starts that bucket's all-reduce there, overlapping the rest of the pass."""
         user_stage = on_stage
+        self._w_keep, self._w_pending, self._w_defer = [], set(), []   # nothing may survive from a pass that raised half way
 
         def on_stage(name):                                   # a bucket is complete only once its weight gradients have landed
             if user_stage is not None:
