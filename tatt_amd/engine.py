@@ -60,7 +60,7 @@ class Engine:
         self.wgrad_mode = os.environ.get("TATT_WGRAD_STREAM", "batch")
         if self.wgrad_mode not in ("batch", "off"):
             raise RuntimeError("TATT_WGRAD_STREAM must be 'batch' or 'off'")
-        self._wside, self.ws_w = None, None
+        self._wside, self.ws_w, self._w_used = None, None, set()
         self._w_keep, self._w_pending, self._w_defer = [], set(), []
 
     # ---- parameters --------------------------------------------------------------------------------
@@ -113,20 +113,29 @@ class Engine:
         if not self._w_defer:
             return
         main = torch.cuda.current_stream()
-        if self._wside is None or self._wside.device != self.dev:
-            self._wside = torch.cuda.Stream(device=self.dev)
-            self.ws_w = torch.empty(WS_FLOATS, device=self.dev, dtype=torch.float32)
-        self._wside.wait_stream(main)
-        with torch.cuda.stream(self._wside):
+        if self._wside is None or self._wside[0].device != self.dev:
+            n = int(os.environ.get("TATT_WGRAD_STREAMS", "2"))
+            self._wside = [torch.cuda.Stream(device=self.dev) for _ in range(n)]
+            self.ws_w = [torch.empty(WS_FLOATS, device=self.dev, dtype=torch.float32) for _ in range(n)]
+            self._w_rr = 0
+        # batches alternate between the weight-gradient streams (no two kernels of a pass write the same gradient tensor, so
+        # the batches are independent of one another); each stream has its own split-K / slab workspace
+        i = self._w_rr % len(self._wside)
+        self._w_rr += 1
+        self._wside[i].wait_stream(main)
+        with torch.cuda.stream(self._wside[i]):
             for fn in self._w_defer:
-                fn(self.ws_w)
+                fn(self.ws_w[i])
         self._w_defer = []
+        self._w_used.add(i)
 
     def _w_join(self):
         """Main stream waits for the weight-gradient stream (before a bucket's all-reduce, the optimiser, or a guarded write)."""
         self._w_flush()
         if self._wside is not None and (self._w_keep or self._w_pending):
-            torch.cuda.current_stream().wait_stream(self._wside)
+            for i in sorted(self._w_used):
+                torch.cuda.current_stream().wait_stream(self._wside[i])
+            self._w_used = set()
             self._w_keep, self._w_pending, self._w_defer = [], set(), []
 
     def _guard(self, t):
