@@ -341,21 +341,40 @@ __global__ void bn_bwd_apply(const float* __restrict__ x, long ldx, const float*
 // ---- LayerNorm over 64 channels: one wave per row, lane = channel ------------------------------------------
 // v = x + dropmask*res (res optional, drop index = row*64 + c) ; y = LN(v)*gamma + beta ; vout (optional) = v
 // optional second output: y2 accumulation  yacc = yscale * y (+ yacc)  (used for the mean over decoder layers)
+__device__ __forceinline__ float sum16(float v) {  // sum over the 16 lanes that share a row
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// 16 lanes per row, 4 channels (one 16-byte access) per lane: a wave works on 4 rows at a time
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, DropCfg dc,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ vout, float* __restrict__ y, int rows, float eps) {
-  const int lane = threadIdx.x & 63;
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  long i = (long)row * 64 + lane;
-  float v = x[i];
-  if (res) v += res[i] * tatt_drop_mask(tatt_eff_seed(dc), (uint32_t)i, dc.thresh, dc.scale);
-  float mean = wave_sum(v) * (1.f / 64.f);
-  float d = v - mean;
-  float var = wave_sum(d * d) * (1.f / 64.f);
-  float rstd = rsqrtf(var + eps);
-  if (vout) vout[i] = v;
-  y[i] = d * rstd * gamma[lane] + beta[lane];
+  const int lane = threadIdx.x & 63, cg = lane & 15;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + (lane >> 4);
+  const bool ok = row < rows;
+  const long i = (long)(ok ? row : 0) * 64 + cg * 4;
+  float4 xv = *reinterpret_cast<const float4*>(x + i);
+  float v[4] = {xv.x, xv.y, xv.z, xv.w};
+  if (res) {
+    const float4 rv = *reinterpret_cast<const float4*>(res + i);
+    const float r[4] = {rv.x, rv.y, rv.z, rv.w};
+    const uint32_t ss = tatt_eff_seed(dc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += r[e] * tatt_drop_mask(ss, (uint32_t)(i + e), dc.thresh, dc.scale);
+  }
+  const float mean = sum16(v[0] + v[1] + v[2] + v[3]) * (1.f / 64.f);
+  float d[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d[e] = v[e] - mean;
+  const float var = sum16(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 64.f);
+  const float rstd = rsqrtf(var + eps);
+  if (!ok) return;
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + cg * 4), be = *reinterpret_cast<const float4*>(beta + cg * 4);
+  if (vout) *reinterpret_cast<float4*>(vout + i) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(y + i) =
+      make_float4(d[0] * rstd * ga.x + be.x, d[1] * rstd * ga.y + be.y, d[2] * rstd * ga.z + be.z, d[3] * rstd * ga.w + be.w);
 }
 
 // dv = rstd*(gamma*dy - mean(gamma*dy) - xhat*mean(gamma*dy*xhat)); dv (+)= ; partial dgamma/dbeta per block.
@@ -364,39 +383,73 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ v
                                                      const float* __restrict__ gamma, float* __restrict__ dv, int dv_accumulate,
                                                      float* __restrict__ dres, DropCfg dc, float* __restrict__ partial, int rows,
                                                      int rows_per_blk, float eps) {
-  __shared__ float red[2][256];
+  __shared__ float red[2][4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cg = lane & 15, rq = lane >> 4;
   const int rb = blockIdx.x * rows_per_blk, re = min(rows, rb + rows_per_blk);
-  const float ga = gamma[lane];
+  const float4 gav = *reinterpret_cast<const float4*>(gamma + cg * 4);
+  const float ga[4] = {gav.x, gav.y, gav.z, gav.w};
   const uint32_t ss = tatt_eff_seed(dc);
-  float sg = 0.f, sb = 0.f;
-  for (int row = rb + w; row < re; row += 4) {
-    long i = (long)row * 64 + lane;
-    float vv = v[i];
-    float mean = wave_sum(vv) * (1.f / 64.f);
-    float d = vv - mean;
-    float var = wave_sum(d * d) * (1.f / 64.f);
-    float rstd = rsqrtf(var + eps);
-    float xh = d * rstd;
-    float g = dy[i] * dyscale;
-    sg += g * xh;
-    sb += g;
-    float gg = g * ga;
-    float m1 = wave_sum(gg) * (1.f / 64.f);
-    float m2 = wave_sum(gg * xh) * (1.f / 64.f);
-    float o = rstd * (gg - m1 - xh * m2);
-    if (dres) dres[i] = o * tatt_drop_mask(ss, (uint32_t)i, dc.thresh, dc.scale);
-    if (dv_accumulate) o += dv[i];
-    dv[i] = o;
+  float sg[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int row0 = rb + w * 4; row0 < re; row0 += 16) {
+    const int row = row0 + rq;
+    const bool ok = row < re;
+    const long i = (long)(ok ? row : rb) * 64 + cg * 4;
+    const float4 vv4 = *reinterpret_cast<const float4*>(v + i), gy4 = *reinterpret_cast<const float4*>(dy + i);
+    const float vv[4] = {vv4.x, vv4.y, vv4.z, vv4.w}, gy[4] = {gy4.x, gy4.y, gy4.z, gy4.w};
+    const float mean = sum16(vv[0] + vv[1] + vv[2] + vv[3]) * (1.f / 64.f);
+    float d[4], xh[4], gg[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = vv[e] - mean;
+    const float var = sum16(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 64.f);
+    const float rstd = rsqrtf(var + eps);
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xh[e] = d[e] * rstd;
+      const float g = ok ? gy[e] * dyscale : 0.f;
+      sg[e] += g * xh[e];
+      sb[e] += g;
+      gg[e] = g * ga[e];
+      p1 += gg[e];
+      p2 += gg[e] * xh[e];
+    }
+    const float m1 = sum16(p1) * (1.f / 64.f), m2 = sum16(p2) * (1.f / 64.f);
+    if (ok) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rstd * (gg[e] - m1 - xh[e] * m2);
+      if (dres) {
+        *reinterpret_cast<float4*>(dres + i) = make_float4(o[0] * tatt_drop_mask(ss, (uint32_t)i, dc.thresh, dc.scale),
+                                                           o[1] * tatt_drop_mask(ss, (uint32_t)(i + 1), dc.thresh, dc.scale),
+                                                           o[2] * tatt_drop_mask(ss, (uint32_t)(i + 2), dc.thresh, dc.scale),
+                                                           o[3] * tatt_drop_mask(ss, (uint32_t)(i + 3), dc.thresh, dc.scale));
+      }
+      if (dv_accumulate) {
+        const float4 pv = *reinterpret_cast<const float4*>(dv + i);
+        o[0] += pv.x; o[1] += pv.y; o[2] += pv.z; o[3] += pv.w;
+      }
+      *reinterpret_cast<float4*>(dv + i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
-  red[0][threadIdx.x] = sg;
-  red[1][threadIdx.x] = sb;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {  // the four rows of the wave, then the four waves
+    sg[e] += __shfl_xor(sg[e], 16, 64);
+    sg[e] += __shfl_xor(sg[e], 32, 64);
+    sb[e] += __shfl_xor(sb[e], 16, 64);
+    sb[e] += __shfl_xor(sb[e], 32, 64);
+  }
+  if (rq == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][w][cg * 4 + e] = sg[e];
+      red[1][w][cg * 4 + e] = sb[e];
+    }
+  }
   __syncthreads();
   if (w == 0) {
-    float a = red[0][lane] + red[0][64 + lane] + red[0][128 + lane] + red[0][192 + lane];
-    float b = red[1][lane] + red[1][64 + lane] + red[1][128 + lane] + red[1][192 + lane];
-    partial[((long)blockIdx.x * 2 + 0) * 64 + lane] = a;
-    partial[((long)blockIdx.x * 2 + 1) * 64 + lane] = b;
+    partial[((long)blockIdx.x * 2 + 0) * 64 + lane] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    partial[((long)blockIdx.x * 2 + 1) * 64 + lane] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
   }
 }
 
@@ -472,8 +525,10 @@ int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const floa
 int tatt_ln_fwd(const float* x, const float* res, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev,
                 const float* gamma,
                 const float* beta, float* vout, float* y, int rows, float eps, hipStream_t st) {
+  TATT_CHECK_ARG(rows > 0 && ((((uintptr_t)x) | ((uintptr_t)res) | ((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)vout) | ((uintptr_t)y)) & 15) == 0,
+                 "tatt_ln_fwd: rows > 0 and 16-byte aligned pointers required");
   DropCfg dc{seed_site, thresh, scale, seed_dev};
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, res, dc, gamma, beta, vout, y, rows, eps);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(rows, 16)), dim3(256), 0, st, x, res, dc, gamma, beta, vout, y, rows, eps);
   TATT_LAUNCH_CHECK("ln_fwd");
   return TATT_OK;
 }
@@ -484,6 +539,8 @@ int tatt_ln_bwd(const float* v, const float* dy, float dyscale, const float* gam
                 uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, float* dgamma, float* dbeta,
                 int accumulate_params, int rows,
                 float eps, float* workspace, hipStream_t st) {
+  TATT_CHECK_ARG(rows > 0 && ((((uintptr_t)v) | ((uintptr_t)dy) | ((uintptr_t)gamma) | ((uintptr_t)dv) | ((uintptr_t)dres)) & 15) == 0,
+                 "tatt_ln_bwd: rows > 0 and 16-byte aligned pointers required");
   DropCfg dc{seed_site, thresh, scale, seed_dev};
   int nblk = cdiv(rows, 64);
   if (nblk > 512) nblk = 512;
