@@ -57,11 +57,13 @@ __global__ __launch_bounds__(256) void prelu_bwd_k(const float* __restrict__ x, 
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 __global__ void sum_partials_k(const float* __restrict__ partial, int n, float scale, float* __restrict__ out, int accumulate) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave: lane l sums partial[l], partial[l + 64], ... (fixed order), then a butterfly -- deterministic, and ~20x shorter
+  // than one thread walking a thousand dependent L2 loads
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
   float s = 0.f;
-  for (int i = 0; i < n; ++i) s += partial[i];
-  s *= scale;
-  out[0] = accumulate ? out[0] + s : s;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+  s = wave_sum(s) * scale;
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
 }
 
 // column sums of [R,C] (ld) : stage 1 partial[blk][C]; blockIdx.x = row block, blockIdx.y = chunk of 1024 columns

@@ -134,12 +134,13 @@ __device__ __forceinline__ float gmap(const float* __restrict__ img, int y, int 
   return sqrtf(a * a + c * c + 1e-6f);
 }
 
-__global__ __launch_bounds__(256) void image_loss_fwd_k(const float* __restrict__ sr, const float* __restrict__ hr,
-                                                        float* __restrict__ per, int C, int H, int W, float w0, float w1) {
-  __shared__ float red[2][4];
+// one 1024-thread workgroup per image (B workgroups of 256 threads left each thread 64 gradient-map evaluations in a row)
+__global__ __launch_bounds__(1024) void image_loss_fwd_k(const float* __restrict__ sr, const float* __restrict__ hr,
+                                                         float* __restrict__ per, int C, int H, int W, float w0, float w1) {
+  __shared__ float red[2][16];
   const int b = blockIdx.x, HW = H * W;
   float mse = 0.f, gl = 0.f;
-  for (int i = threadIdx.x; i < C * HW; i += 256) {
+  for (int i = threadIdx.x; i < C * HW; i += 1024) {
     int c = i / HW, p = i - c * HW;
     float d = sr[(long)b * C * HW + i] - hr[(long)b * C * HW + i];
     mse += d * d;
@@ -157,7 +158,11 @@ __global__ __launch_bounds__(256) void image_loss_fwd_k(const float* __restrict_
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float m = red[0][0] + red[0][1] + red[0][2] + red[0][3], g = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    float m = 0.f, g = 0.f;
+    for (int k = 0; k < 16; ++k) {
+      m += red[0][k];
+      g += red[1][k];
+    }
     per[b] = w0 * m / (float)(C * HW) + w1 * g / (float)(3 * HW);
   }
 }
@@ -208,9 +213,12 @@ __global__ __launch_bounds__(256) void sumsq_partial_k(const float* __restrict__
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 __global__ void clip_final_k(const float* __restrict__ partial, int n, float max_norm, float b1, float b2, float* __restrict__ state) {
-  if (threadIdx.x != 0) return;
+  // one wave, double accumulation: lane l takes partial[l], partial[l + 64], ..., then a butterfly (fixed order)
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += (double)partial[i];
+  for (int i = threadIdx.x; i < n; i += 64) s += (double)partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x != 0) return;
   float norm = (float)sqrt(s);
   state[0] = norm;
   float coef = max_norm / (norm + 1e-6f);
@@ -261,7 +269,7 @@ int tatt_rotate_bwd(const float* arc, const float* dy, float* dx, int B, int C, 
   return TATT_OK;
 }
 int tatt_image_loss_fwd(const float* sr, const float* hr, float* per, int B, int C, int H, int W, float w0, float w1, hipStream_t st) {
-  hipLaunchKernelGGL(image_loss_fwd_k, dim3(B), dim3(256), 0, st, sr, hr, per, C, H, W, w0, w1);
+  hipLaunchKernelGGL(image_loss_fwd_k, dim3(B), dim3(1024), 0, st, sr, hr, per, C, H, W, w0, w1);
   TATT_LAUNCH_CHECK("image_loss_fwd");
   return TATT_OK;
 }
