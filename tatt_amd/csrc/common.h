@@ -88,8 +88,18 @@ __device__ __forceinline__ float block16_colsum(const float* __restrict__ partia
                                                 float* red) {
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   float s = 0.f;
-  if (cvalid)
-    for (int b = rl; b < nblk; b += 16) s += partial[(long)b * stride_b + c];
+  if (cvalid) {  // four independent chains: the loads of a trip are in flight together (one chain = nblk/16 dependent L2 trips)
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = rl;
+    for (; b + 48 < nblk; b += 64) {
+      s += partial[(long)b * stride_b + c];
+      s1 += partial[(long)(b + 16) * stride_b + c];
+      s2 += partial[(long)(b + 32) * stride_b + c];
+      s3 += partial[(long)(b + 48) * stride_b + c];
+    }
+    for (; b < nblk; b += 16) s += partial[(long)b * stride_b + c];
+    s = (s + s1) + (s2 + s3);
+  }
   red[rl * 16 + cl] = s;
   __syncthreads();
   float t = 0.f;
