@@ -52,6 +52,7 @@ class Engine:
         self.seed_dev = None      # optional uint32 device tensor added to the dropout seed (graph-captured training)
         self.wpack = {}
         self._side = None         # side stream of the RPE recurrence (see forward)
+        self._nbt = []            # BatchNorm num_batches_tracked buffers touched by the running forward pass
         # Weight-gradient kernels are leaves of the backward pass: nothing downstream reads dW before the optimiser.  In "batch"
         # mode they are collected and issued in groups on their own stream (a parallel branch of the captured hipGraph), so that
         # their ramp-up and under-filled tails overlap with the dgrad chain; see _wgrad().  "off" = in line on the main stream.
@@ -262,7 +263,7 @@ class Engine:
         stat = self.new(2, C)
         if train:
             self.L.bn_stats(x, C, R, C, 1e-5, 0.1, stat, P[pre + "running_mean"], P[pre + "running_var"], self.ws)
-            P[pre + "num_batches_tracked"] += 1
+            self._nbt.append(P[pre + "num_batches_tracked"])    # bumped together at the end of forward (one launch, not 18)
         else:
             self.L.bn_stat_from_running(P[pre + "running_mean"], P[pre + "running_var"], C, 1e-5, stat)
         y = out if out is not None else self.new(R, C)
@@ -408,6 +409,7 @@ class Engine:
         L, m = self.L, self.m
         self.refresh()
         P = self.P
+        self._nbt = []
         B, C, H, W = x.shape
         if (C, H, W) != (4, 16, 64):
             raise RuntimeError(f"expected LR input [B,4,16,64], got {tuple(x.shape)}")
@@ -572,6 +574,9 @@ class Engine:
         ctx["tail"] = (blk, c7, st7, u_in, cu, up, pre_s)
         ctx["sr"] = sr
         ctx["use_stn"] = use_stn
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)
+            self._nbt = []
         return sr, ctx
 
     # ================================================================================================================
