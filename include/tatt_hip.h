@@ -103,6 +103,10 @@ int tatt_attn_avg(const float* pw, float* out, int B, int Lq, hipStream_t stream
 int tatt_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, hipStream_t stream);
 int tatt_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, hipStream_t stream);
 int tatt_axpby(const float* a, float alpha, const float* b, float beta, float* out, long n, int accumulate, hipStream_t stream);
+/* n <= 64 contiguous float segments src[i][0..len[i]) copied to dst + dst_off[i] by one launch (host arrays).  Used to stack the
+ * forward / reverse nn.GRU input weights of every BiGRU block ([96,64] + [96,64] -> [192,64], model/tsrn.py GruBlock) so that
+ * both directions' input projections are one GEMM. */
+int tatt_multi_copy(int n, const float* const* src, const long* dst_off, const long* len, float* dst, hipStream_t stream);
 int tatt_prelu_fwd(const float* x, const float* slope, float* y, long n, hipStream_t stream);
 int tatt_prelu_bwd(const float* x, const float* slope, const float* dy, float* dx, float* dslope, int accumulate, long n, float* workspace, hipStream_t stream);
 size_t tatt_colsum_workspace(int C);

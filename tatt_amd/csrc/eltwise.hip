@@ -144,6 +144,19 @@ __global__ void colsum_final_k(const float* __restrict__ partial, int nblk, int 
   out[c] = accumulate ? out[c] + s : s;
 }
 
+// up to MC_MAX contiguous segments gathered into one buffer by one launch (blockIdx.y = segment)
+constexpr int MC_MAX = 64;
+struct MultiCopy {
+  const float* src[MC_MAX];
+  long dst_off[MC_MAX], len[MC_MAX];
+};
+__global__ void multi_copy_k(MultiCopy mc, float* __restrict__ dst) {
+  const int sgm = blockIdx.y;
+  const float* __restrict__ s = mc.src[sgm];
+  float* __restrict__ d = dst + mc.dst_off[sgm];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < mc.len[sgm]; i += (long)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 // PixelShuffle(2)+mish: in NHWC [B,H,W,4C] (channel c*4 + i*2 + j) -> out NHWC [B,2H,2W,C]
 __global__ void pixshuf_mish_fwd_k(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -313,6 +326,22 @@ int tatt_prelu_bwd(const float* x, const float* slope, const float* dy, float* d
   TATT_LAUNCH_CHECK("prelu_bwd");
   hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(64), 0, st, workspace, nblk, 1.0f, dslope, accumulate);
   TATT_LAUNCH_CHECK("prelu_bwd_final");
+  return TATT_OK;
+}
+int tatt_multi_copy(int n, const float* const* src, const long* dst_off, const long* len, float* dst, hipStream_t st) {
+  TATT_CHECK_ARG(n > 0 && n <= MC_MAX && src && dst_off && len && dst, "tatt_multi_copy: 1..%d segments, non-null arrays", MC_MAX);
+  MultiCopy mc;
+  long mx = 0;
+  for (int i = 0; i < n; ++i) {
+    TATT_CHECK_ARG(src[i] && len[i] >= 0 && dst_off[i] >= 0, "tatt_multi_copy: bad segment %d", i);
+    mc.src[i] = src[i]; mc.dst_off[i] = dst_off[i]; mc.len[i] = len[i];
+    if (len[i] > mx) mx = len[i];
+  }
+  int bx = cdiv(mx, 256 * 4);
+  if (bx < 1) bx = 1;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(multi_copy_k, dim3(bx, n), dim3(256), 0, st, mc, dst);
+  TATT_LAUNCH_CHECK("multi_copy");
   return TATT_OK;
 }
 size_t tatt_colsum_workspace(int C) { return (size_t)256 * C; }

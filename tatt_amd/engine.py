@@ -289,6 +289,32 @@ class Engine:
             return (B * W, H, W, H * W, 1, W)
         return (B * H, W, 1, W, 0, 1)
 
+    def _gru_pack(self):
+        """W_ih / b_ih of the forward and reverse direction of every BiGRU block stacked as [n][192][64] / [n][192], gathered by
+        one launch per forward call (tatt_multi_copy): both directions' input projections (and their input gradient) are then
+        one GEMM with N (K) = 192 instead of two with 96."""
+        pk = self.wpack.get("gru")
+        if pk is None:
+            pres = [f"block{i + 2}.gru{j}." for i in range(self.m.srb_nums) for j in (1, 2)]
+            n = len(pres)
+            Wp, bp = self.new(n, 192, 64), self.new(n, 192)
+            src, off, ln = [], [], []
+            for i, pre in enumerate(pres):
+                for d, sfx in enumerate(["", "_reverse"]):
+                    src += [self.P[pre + "gru.weight_ih_l0" + sfx], self.P[pre + "gru.bias_ih_l0" + sfx]]
+                    off += [(i * 192 + d * 96) * 64, n * 192 * 64 + i * 192 + d * 96]
+                    ln += [96 * 64, 96]
+            buf = self.new(n * 192 * 64 + n * 192)
+            k = len(src)
+            for c0 in range(0, k, 64):
+                c1 = min(k, c0 + 64)
+                m = c1 - c0
+                self.L.multi_copy(m, (ctypes.c_void_p * m)(*[t.data_ptr() for t in src[c0:c1]]), (ctypes.c_long * m)(*off[c0:c1]),
+                                  (ctypes.c_long * m)(*ln[c0:c1]), buf)
+            Wp, bp = buf[:n * 192 * 64].view(n, 192, 64), buf[n * 192 * 64:].view(n, 192)
+            pk = self.wpack["gru"] = (Wp, bp, {pre: i for i, pre in enumerate(pres)})
+        return pk
+
     def gru_block_fwd(self, pre, inputs, B, H, W, vertical, save, ctx, key):
         """inputs: list of (x[R,Kc], column offset in conv1.weight, Kc).  Returns out [R,64]."""
         P, R = self.P, B * H * W
@@ -298,8 +324,8 @@ class Engine:
         for i, (x, off, kc) in enumerate(inputs):
             self.linear(x, Wc.view(-1)[off:], P[pre + "conv1.bias"] if i == 0 else None, g_in, R, 64, kc, ldw=Ktot, acc=int(i > 0))
         gi = self.new(R, 192)
-        self.linear(g_in, P[pre + "gru.weight_ih_l0"], P[pre + "gru.bias_ih_l0"], gi, R, 96, 64, ldc=192)
-        self.linear(g_in, P[pre + "gru.weight_ih_l0_reverse"], P[pre + "gru.bias_ih_l0_reverse"], gi.view(-1)[96:], R, 96, 64, ldc=192)
+        Wp, bp, ix = self._gru_pack()
+        self.linear(g_in, Wp[ix[pre]], bp[ix[pre]], gi, R, 192, 64)
         out = self.new(R, 64)
         sv = self.new(R, 2, 4, 32) if save else None
         self.L.gru32_fwd(gi, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], P[pre + "gru.bias_hh_l0"],
@@ -321,7 +347,8 @@ class Engine:
             gi_d, gh_d, hp_d = dgi.view(-1)[96 * d:], dgh.view(-1)[96 * d:], hprev.view(-1)[32 * d:]
             wg.append((gh_d, hp_d, G[pre + "gru.weight_hh_l0" + sfx], G[pre + "gru.bias_hh_l0" + sfx], R, 96, 32, 192, 64, None))
             wg.append((gi_d, g_in, G[pre + "gru.weight_ih_l0" + sfx], G[pre + "gru.bias_ih_l0" + sfx], R, 96, 64, 192, None, None))
-            self.linear_dx(gi_d, P[pre + "gru.weight_ih_l0" + sfx], dg_in, R, 96, 64, lddy=192, acc=d)
+        Wp, _, ix = self._gru_pack()
+        self.linear_dx(dgi, Wp[ix[pre]], dg_in, R, 192, 64)
         Wc, dWc = P[pre + "conv1.weight"], G[pre + "conv1.weight"]
         Ktot = Wc.shape[1]
         for i, (x, off, kc, dx, acc) in enumerate(inputs):
