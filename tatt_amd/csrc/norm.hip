@@ -216,10 +216,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ x
       for (int e = 0; e < 4; ++e) {
         mean[e] = stat[cl4 * 4 + e]; inv[e] = stat[C + cl4 * 4 + e]; ga[e] = gamma[cl4 * 4 + e]; be[e] = beta[cl4 * 4 + e];
       }
-      for (int r = rb + rl4; r < re; r += RL4) {
-        float4 xv = *reinterpret_cast<const float4*>(x + (long)r * ldx + cl4 * 4);
-        float4 gv = *reinterpret_cast<const float4*>(dy + (long)r * lddy + cl4 * 4);
-        float xi[4] = {xv.x, xv.y, xv.z, xv.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w};
+      auto acc1 = [&](const float4& xv, const float4& gv) {
+        const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float xh = (xi[e] - mean[e]) * inv[e];
@@ -227,7 +225,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ x
           a1[e] += g;
           a2[e] += g * xh;
         }
+      };
+      int r = rb + rl4;
+      for (; r + 3 * RL4 < re; r += 4 * RL4) {  // eight 16-byte loads in flight per thread (one wave per SIMD: nothing else hides them)
+        float4 xv[4], gv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          xv[k] = *reinterpret_cast<const float4*>(x + (long)(r + k * RL4) * ldx + cl4 * 4);
+          gv[k] = *reinterpret_cast<const float4*>(dy + (long)(r + k * RL4) * lddy + cl4 * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc1(xv[k], gv[k]);
       }
+      for (; r < re; r += RL4)
+        acc1(*reinterpret_cast<const float4*>(x + (long)r * ldx + cl4 * 4), *reinterpret_cast<const float4*>(dy + (long)r * lddy + cl4 * 4));
     }
     r1[tid] = make_float4(a1[0], a1[1], a1[2], a1[3]);
     r2[tid] = make_float4(a2[0], a2[1], a2[2], a2[3]);
