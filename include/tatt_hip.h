@@ -11,7 +11,8 @@
  *     kept values are multiplied by scale = 1/(1-p); thresh == 0 disables dropout; seed_dev (optional device
  *     pointer) adds seed_dev[0] to the seed at run time so a captured hipGraph draws new masks per replay.
  * tatt_amd/lib.py parses this header to build the ctypes signatures: keep one declaration per statement and
- * use only the scalar types  int, long, float, uint32_t, size_t, hipStream_t  and (const) float* / void*.
+ * use only the scalar types  int, long, float, uint32_t, size_t, hipStream_t; every pointer argument (whatever it points to) is
+ * passed as void*.  Arguments documented as HOST arrays (the grouped entry points) are read during the call, not later.
  */
 #ifndef TATT_HIP_H
 #define TATT_HIP_H
@@ -57,6 +58,8 @@ int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, flo
  * strides (T*Cin, 1, 0, Cin), and Wd[ci][tap][co] with the taps already flipped for dgrad, strides (T*Cout, 1, 0, Cout):
  * the kernel's weight-tile loads become 16-byte contiguous instead of stride-T gathers. */
 int tatt_conv_pack_w(const float* Wt, float* Wf, float* Wd, int Cout, int Cin, int KH, int KW, hipStream_t stream);
+/* The same for n <= 32 layers in one launch (host arrays of length n; KHW[i] = KH*KW of layer i). */
+int tatt_conv_pack_w_group(int n, const float* const* Wt, float* const* Wf, float* const* Wd, const int* Cout, const int* Cin, const int* KHW, hipStream_t stream);
 /* Cout in {4,8,16} (9x9 64->4 output conv model/tsrn.py:625 and the dgrad of the 9x9 4->64 conv :598): dense planar GEMM
  * Z[(tap,co)][pixel] followed by a shifted gather-sum, instead of padding Cout to the 64-wide MFMA tile. */
 size_t tatt_conv_skinny_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW);

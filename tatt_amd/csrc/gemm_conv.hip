@@ -598,6 +598,29 @@ __global__ void conv_pack_w_kernel(const float* __restrict__ Wt, float* __restri
   }
 }
 
+// the same for up to PACK_MAX layers in one launch (blockIdx.y = layer)
+constexpr int PACK_MAX = 32;
+struct PackGroup {
+  const float* Wt[PACK_MAX];
+  float* Wf[PACK_MAX];
+  float* Wd[PACK_MAX];
+  int Cout[PACK_MAX], Cin[PACK_MAX], T[PACK_MAX];
+};
+__global__ void conv_pack_w_group_kernel(PackGroup g) {
+  const int l = blockIdx.y, Cout = g.Cout[l], Cin = g.Cin[l], T = g.T[l];
+  const float* __restrict__ Wt = g.Wt[l];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Cout * Cin * T; i += gridDim.x * blockDim.x) {
+    {
+      const int ci = i % Cin, tap = (i / Cin) % T, co = i / (Cin * T);
+      g.Wf[l][i] = Wt[((long)co * Cin + ci) * T + tap];
+    }
+    {
+      const int co = i % Cout, tap = (i / Cout) % T, ci = i / (Cout * T);
+      g.Wd[l][i] = Wt[((long)co * Cin + ci) * T + (T - 1 - tap)];
+    }
+  }
+}
+
 __global__ void skinny_repack_w(const float* __restrict__ Wt, float* __restrict__ Wr, int Cin, int Cout, int T, long w_sn, long w_sci,
                                 long w_base, long w_stap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;  // (tap, co, ci)
@@ -684,6 +707,26 @@ int tatt_conv_pack_w(const float* Wt, float* Wf, float* Wd, int Cout, int Cin, i
   const int n = Cout * Cin * KH * KW;
   hipLaunchKernelGGL(conv_pack_w_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, Wt, Wf, Wd, Cout, Cin, KH * KW);
   TATT_LAUNCH_CHECK("conv_pack_w_kernel");
+  return TATT_OK;
+}
+
+// tatt_conv_pack_w for n <= 32 layers in one launch; host arrays of length n (Wf[i], Wd[i]: Cout[i]*Cin[i]*KH[i]*KW[i] floats each).
+int tatt_conv_pack_w_group(int n, const float* const* Wt, float* const* Wf, float* const* Wd, const int* Cout, const int* Cin,
+                           const int* KHW, hipStream_t st) {
+  TATT_CHECK_ARG(n > 0 && n <= PACK_MAX && Wt && Wf && Wd && Cout && Cin && KHW, "tatt_conv_pack_w_group: 1..%d layers, non-null arrays", PACK_MAX);
+  PackGroup g;
+  memset(&g, 0, sizeof(g));
+  long mx = 0;
+  for (int i = 0; i < n; ++i) {
+    TATT_CHECK_ARG(Wt[i] && Wf[i] && Wd[i] && Cout[i] > 0 && Cin[i] > 0 && KHW[i] > 0, "tatt_conv_pack_w_group: bad layer %d", i);
+    g.Wt[i] = Wt[i]; g.Wf[i] = Wf[i]; g.Wd[i] = Wd[i]; g.Cout[i] = Cout[i]; g.Cin[i] = Cin[i]; g.T[i] = KHW[i];
+    const long e = (long)Cout[i] * Cin[i] * KHW[i];
+    if (e > mx) mx = e;
+  }
+  int bx = cdiv(mx, 256 * 4);
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(conv_pack_w_group_kernel, dim3(bx, n), dim3(256), 0, st, g);
+  TATT_LAUNCH_CHECK("conv_pack_w_group_kernel");
   return TATT_OK;
 }
 

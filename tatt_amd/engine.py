@@ -207,6 +207,34 @@ class Engine:
         z = self.new(wsz)                                      # planar Z [(tap,co)][pixel]: 340 MB for the output conv at B=64
         self.L.conv_skinny_fwd(x, W, b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout, *wstr, acc, z)
 
+    def _prepack(self, use_stn):
+        """Pack every convolution weight of the network for this forward call with ONE launch (tatt_conv_pack_w_group)."""
+        m, P = self.m, self.P
+        names = ["block1.0.weight"]
+        for i in range(m.srb_nums):
+            names += [f"block{i + 2}.conv1.weight", f"block{i + 2}.conv2.weight"]
+        names += [f"block{m.srb_nums + 2}.0.weight", f"block{m.srb_nums + 3}.0.conv.weight"]
+        if use_stn:
+            names += [f"stn_head.stn_convnet.{idx}.0.weight" for idx, *_ in STN_STAGES]
+        Ws = [P[n] for n in names if P[n].data_ptr() not in self.wpack]
+        if not Ws:
+            return
+        tot = sum(w.numel() for w in Ws)
+        buf = self.new(2 * tot)
+        outs, o = [], 0
+        for w in Ws:
+            outs.append((buf[o:o + w.numel()], buf[tot + o:tot + o + w.numel()]))
+            o += w.numel()
+        for c0 in range(0, len(Ws), 32):
+            ws_, os_ = Ws[c0:c0 + 32], outs[c0:c0 + 32]
+            n = len(ws_)
+            VP, IN = ctypes.c_void_p * n, ctypes.c_int * n
+            self.L.conv_pack_w_group(n, VP(*[w.data_ptr() for w in ws_]), VP(*[a.data_ptr() for a, _ in os_]),
+                                     VP(*[b.data_ptr() for _, b in os_]), IN(*[w.shape[0] for w in ws_]), IN(*[w.shape[1] for w in ws_]),
+                                     IN(*[w.shape[2] * w.shape[3] for w in ws_]))
+        for w, pk in zip(Ws, outs):
+            self.wpack[w.data_ptr()] = pk
+
     def _packed(self, W, Cout, Cin, k):
         """(Wf [co][tap][ci], Wd [ci][flipped tap][co]) of an OIHW weight, packed once per forward call (tatt_conv_pack_w)."""
         key = W.data_ptr()
@@ -453,6 +481,8 @@ class Engine:
         R0 = B * H * W
         use_stn = bool(m.stn and training)
         ctx["x"] = x
+        self._prepack(use_stn)
+        self._gru_pack()
 
         # ---- recurrent positional encoding (model/transformer_v2.py:215-221): GRU over the batch axis, identical input at
         # every step.  It depends on weights only and is a chain of B dependent, latency-bound launches, so it is forked
