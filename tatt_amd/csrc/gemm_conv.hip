@@ -500,9 +500,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   };
 
   // tile t+1 sits in register set (t+1)&1, tile t+2 in set t&1
+  // tiles 0 and 1 are requested back to back (two register sets), tile 2 as soon as tile 0 has been parked in LDS: the
+  // short-K launches (K = 64..192: two to six tiles) are one memory latency shorter than with "load, store, load, load"
   load_tiles(kbeg, ra0, rb0);
-  store_tiles(0, ra0, rb0);
   load_tiles(kbeg + BK, ra1, rb1);
+  store_tiles(0, ra0, rb0);
   load_tiles(kbeg + 2 * BK, ra0, rb0);
   __syncthreads();
   // Two tiles per trip, no early exit: an odd tile count multiplies one all-zero tile (loads past kend are predicated off).
