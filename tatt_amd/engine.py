@@ -280,7 +280,7 @@ class Engine:
             tiles = -(-(T * Cin) // 128)
         else:                                                  # M = Cout, N = T*Cin
             tiles = -(-Cout // 128) * -(-(T * Cin) // 64)
-        sk = max(1, min((B * H * Wd) // 256, -(-1024 // tiles)))
+        sk = max(1, min((B * H * Wd) // 256, -(-768 // tiles)))        # ~3 workgroups per CU (swept 256..1536: flat within 1 %)
         while sk > 1 and Cout * T * Cin * sk > WS_FLOATS:
             sk //= 2
         self._wgrad(lambda ws: self.L.conv_wgrad(x, dy, dW, B, H, Wd, Cin, Cout, k, k, Cin, Cout, sk, ws, 1), [dy], [x])
