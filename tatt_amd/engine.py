@@ -458,8 +458,10 @@ class Engine:
         return dres
 
     # ================================================================================================================
-    def forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True, wpack=None):
-        """wpack: the packed conv weights of an earlier forward call on the SAME weights (the TSC step runs the network
+    def forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True, wpack=None, tp_ready=None):
+        """tp_ready: optional torch.cuda.Event after which `text_emb` may be read (the prior generator may still be running on
+        another stream while the STN head, block1 and the RPE chain -- which do not need the prior -- are under way).
+        wpack: the packed conv weights of an earlier forward call on the SAME weights (the TSC step runs the network
         twice per optimiser step) — skips the repack."""
         L, m = self.L, self.m
         self.refresh()
@@ -557,6 +559,8 @@ class Engine:
         # ---- TP interpreter (model/tsrn.py:194-226, model/transformer_v2.py:198-244) -----------------------------------
         Rt = B * 26
         tpr = self.new(Rt, K)
+        if tp_ready is not None:
+            torch.cuda.current_stream().wait_event(tp_ready)
         L.tp_rows(text_emb, text_emb.stride(0), text_emb.stride(1), text_emb.stride(3), tpr, B, K, 26)
         t0 = self.new(Rt, 64)
         self.linear(tpr, P[ig + "fc_in.weight"], P[ig + "fc_in.bias"], t0, Rt, 64, K)

@@ -108,11 +108,11 @@ class SRTrainer:
         start = torch.argsort(per)[int(keep_proportion * B)]
         return (torch.arange(B, device=per.device) < start).to(per.dtype)
 
-    def _fwd_bwd(self, lr_img, hr_img, tp, overlap, arc=None):
+    def _fwd_bwd(self, lr_img, hr_img, tp, overlap, arc=None, tp_ready=None):
         L, B = self.L, lr_img.shape[0]
         self.flat_g.zero_()
         L.seed_bump(self.seed_dev)
-        sr, ctx = self.eng.forward(lr_img, tp, True, 0)
+        sr, ctx = self.eng.forward(lr_img, tp, True, 0, tp_ready=tp_ready)
         C, H, W = sr.shape[1:]
         per = torch.empty(B, device=sr.device)
         L.image_loss_fwd(sr, hr_img, per, B, C, H, W, self.loss_weight[0], self.loss_weight[1])
@@ -275,16 +275,25 @@ class TATTTrainer(SRTrainer):
         side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
             logits_t = self.teacher.forward_from_images(hr_img)                          # [26, B, K]
+        # the student's forward pass runs on a stream of its own as well: the SR step only needs its prior at the TP interpreter,
+        # after the STN head and block1 (Engine.forward(tp_ready=...))
+        if getattr(self, "_st_stream", None) is None:
+            self._st_stream = torch.cuda.Stream(device=lr_img.device)
+        st = self._st_stream
+        st.wait_stream(main)
         plan = self.student.plan()
-        x4 = torch.empty(B, 32, 100, 4, device=lr_img.device)
-        L.crnn_prep(lr_img, x4, B, lr_img.shape[1], lr_img.shape[2], lr_img.shape[3], 32, 100)
-        logits_s, ctx_s = plan.forward(x4, B, 100, True, want_ctx=True)
-        T = logits_s.shape[0]
-        probs = torch.empty(T, B, K, device=lr_img.device)
-        L.softmax_rows(logits_s, probs, T * B, K)
+        with torch.cuda.stream(st):
+            x4 = torch.empty(B, 32, 100, 4, device=lr_img.device)
+            L.crnn_prep(lr_img, x4, B, lr_img.shape[1], lr_img.shape[2], lr_img.shape[3], 32, 100)
+            logits_s, ctx_s = plan.forward(x4, B, 100, True, want_ctx=True)
+            T = logits_s.shape[0]
+            probs = torch.empty(T, B, K, device=lr_img.device)
+            L.softmax_rows(logits_s, probs, T * B, K)
+            tp_ready = torch.cuda.Event()
+            tp_ready.record(st)
         prior = probs.permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)                 # label_vecs_final: the [B,K,1,26] view
         # L_TP and the student's backward pass (everything they read was produced above and stays alive until the join)
-        side.wait_stream(main)
+        side.wait_stream(st)
         with torch.cuda.stream(side):
             self.s_g.zero_()
             self.loss_tp = torch.empty(1, device=lr_img.device)
@@ -292,7 +301,7 @@ class TATTTrainer(SRTrainer):
             ws = torch.empty(L.semantic_loss_workspace(T * B), device=lr_img.device)
             L.semantic_loss(logits_s, logits_t, self.loss_tp, dz, 100.0, T * B, K, ws)
             plan.backward(ctx_s, dz.view(T, B, K), self.G_s)
-        per, works = super()._fwd_bwd(lr_img, hr_img, prior, overlap, arc=arc)
+        per, works = super()._fwd_bwd(lr_img, hr_img, prior, overlap, arc=arc, tp_ready=tp_ready)
         main.wait_stream(side)
         if overlap:
             works.append(allreduce_mean(self.s_g, async_op=True))
