@@ -189,9 +189,9 @@ def test_batchnorm_train_fwd_bwd(R_, C, act):
     close(db, b_.grad, tol, "bn dbeta")
 
 
+@pytest.mark.parametrize("rows", [1000, 1, 19, 1664])
 @pytest.mark.parametrize("p", [0.0, 0.1])
-def test_layernorm_residual_dropout(p):
-    rows = 1000
+def test_layernorm_residual_dropout(p, rows):
     x, res = rnd(rows, 64).requires_grad_(True), rnd(rows, 64, seed=1).requires_grad_(True)
     g_, b_ = (1 + 0.2 * rnd(64, seed=2)).requires_grad_(True), rnd(64, seed=3).requires_grad_(True)
     drop = R.HashDropout(p, 7)
