@@ -178,12 +178,12 @@ def test_state_dict_contract_and_buffers():
     assert tuple(y.shape) == (1, 4, 32, 128) and torch.isfinite(y).all()
 
 
-def test_full_batch_properties():
-    """BASELINE config 2 size (B=64): finite outputs in (0,1); per-sample independence of the eval path
+@pytest.mark.parametrize("B", [64, 97])
+def test_full_batch_properties(B):
+    """BASELINE config 2 size (B=64) and a ragged larger batch (97): finite outputs in (0,1); per-sample independence of the eval path
     (sample i of a batch == the same sample in a batch of 1 is NOT expected because the RPE recurs over the
     batch axis — SURVEY §8a a7 — so instead check prefix consistency: the forward direction of the RPE makes
     query_pos of sample 0 depend on nothing else)."""
-    B = 64
     m = build().train()
     hr, lr, tp = procgen.make_inputs(B, 37, seed=4)
     sr = m(lr.cuda(), tp.cuda())
