@@ -643,7 +643,7 @@ class Engine:
     # ================================================================================================================
     def backward(self, ctx, dsr, G, on_stage=None):
         """Accumulates parameter gradients of one forward call into G (dict name -> fp32 tensor).
-        on_stage(name) is called when a gradient bucket is complete ("tail", "srbs", "head", "infogen" -- the RPE chain finishes last):
+        on_stage(name) is called when a gradient bucket is complete ("tail", "srbs", then "head" and "infogen" together at the end):
         the data-parallel trainer starts that bucket's all-reduce there, overlapping the rest of the pass."""
         user_stage = on_stage
         self._w_keep, self._w_pending, self._w_defer = [], set(), []   # nothing may survive from a pass that raised half way
@@ -739,6 +739,7 @@ class Engine:
             dnext = dtgt
         axpby(dnext, 1.0, None, 0.0, db1, R0 * 64, 1)
         axpby(dkin, 1.0, None, 0.0, dmem, Rt * 64, 1)                     # kin = mem + pos
+        self._w_flush()                                                        # the decoder's weight gradients start now
         # recurrent positional encoding, BPTT over the batch axis: dqp is complete here.  The chain of B latency-bound
         # launches runs on the side stream beside the encoder / block1 / STN backward; its weight-gradient GEMMs (which
         # need the shared workspace) follow after the join at the end of the pass.
@@ -767,7 +768,6 @@ class Engine:
                 self.colsum(dgi_sum[dd], 64, 1536, G[g + "bias_ih_l0" + sfx])
                 self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd, splitk=8)
             L.rpe_scatter_dx(dxg, G[ig + "init_factor.weight"], 1)
-            on_stage("infogen")
         # encoder
         e = tr + "encoder.layers.0."
         ds1 = self.new(Rt, 64)
@@ -784,6 +784,7 @@ class Engine:
         dt0 = self.new(Rt, 64)
         L.prelu_bwd(t0, P[ig + "activation.weight"], dt, dt0, G[ig + "activation.weight"], 1, Rt * 64, self.ws)
         self.linear_dwb(dt0, tpr, G[ig + "fc_in.weight"], G[ig + "fc_in.bias"], Rt, 64, K)
+        self._w_flush()
 
         # ---- block1 ------------------------------------------------------------------------------------------------
         dc1 = self.new(R0, 64)
@@ -791,8 +792,9 @@ class Engine:
         xs = ctx["xs"]
         self.conv_wgrad(xs, dc1, G["block1.0.weight"], G["block1.0.bias"], B, H, W, 4, 64, 9)
         if not ctx["use_stn"]:
-            on_stage("head")
             rpe_finish()
+            on_stage("head")
+            on_stage("infogen")
             return
         # ---- TPS + STN head ----------------------------------------------------------------------------------------
         stn_saved, f, l1, stat1, feat01, ctrl, Tm = ctx["stn"]
@@ -800,6 +802,10 @@ class Engine:
         self.conv_dgrad(dc1, P["block1.0.weight"], dxs, B, H, W, 4, 64, 9)
         dctrl = self.new(B, 40)
         L.tps_sample_bwd(ctx["x"], ctrl, Tm, dxs, dctrl, B, 4, H, W, 0)
+        # The RPE chain (forked after the decoder) has ended by now at the benchmark shapes: its input-gradient GEMMs go here and
+        # its weight gradients join the queue, so that they overlap with the STN head's backward pass instead of trailing it.
+        rpe_finish()
+        self._w_flush()
         self.linear_dw(dctrl, feat01, G["stn_head.stn_fc2.weight"], B, 40, 512)
         self.colsum(dctrl, B, 40, G["stn_head.stn_fc2.bias"])
         dfeat = self.new(B, 512)
@@ -828,8 +834,10 @@ class Engine:
             if idx > 0:
                 dh = self.new(Rr, cin)
                 self.conv_dgrad(dc, P[pre + "0.weight"], dh, B, hh, ww, cin, cout, 3)
+            if idx in (8, 4):
+                self._w_flush()
         on_stage("head")
-        rpe_finish()
+        on_stage("infogen")
 
 
 # parameters that never receive a gradient in the reference: autograd must see None for them
