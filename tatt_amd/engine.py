@@ -52,6 +52,7 @@ class Engine:
         self.seed_dev = None      # optional uint32 device tensor added to the dropout seed (graph-captured training)
         self.wpack = {}
         self._side = None         # side stream of the RPE recurrence (see forward)
+        self._enc = None          # stream of the TP interpreter's text branch (forward)
         self._nbt = []            # BatchNorm num_batches_tracked buffers touched by the running forward pass
         # Weight-gradient kernels are leaves of the backward pass: nothing downstream reads dW before the optimiser.  In "batch"
         # mode they are collected and issued in groups on their own stream (a parallel branch of the captured hipGraph), so that
@@ -143,6 +144,11 @@ class Engine:
         """Call before the main stream writes `t` in place: if a pending weight-gradient kernel still reads it, join first."""
         if self._w_pending and t is not None and t.untyped_storage().data_ptr() in self._w_pending:
             self._w_join()
+
+    def enc_stream(self):
+        if self._enc is None or self._enc.device != self.dev:
+            self._enc = torch.cuda.Stream(device=self.dev)
+        return self._enc
 
     def new(self, *shape):
         return torch.empty(shape, device=self.dev, dtype=torch.float32)
@@ -509,6 +515,34 @@ class Engine:
                 L.rpe_step_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], hstep[0, s + 1],
                                gh_all[0, s], qp, s, B, dsg, dsh)
 
+        # ---- text branch of the TP interpreter (fc_in, PReLU, positional encoding, encoder layer): it reads the prior and weights
+        # only, so it runs on a stream of its own beside the STN head / block1 (and the RPE chain) until the decoder needs it
+        enc = self.enc_stream() if tp_ready is None else main    # (with a prior still in flight there are enough strands already:
+        enc.wait_stream(main)                                    #  the whole-iteration step got slower with one more)
+        with torch.cuda.stream(enc):
+            Rt = B * 26
+            tpr = self.new(Rt, K)
+            if tp_ready is not None:
+                enc.wait_event(tp_ready)
+            L.tp_rows(text_emb, text_emb.stride(0), text_emb.stride(1), text_emb.stride(3), tpr, B, K, 26)
+            t0 = self.new(Rt, 64)
+            self.linear(tpr, P[ig + "fc_in.weight"], P[ig + "fc_in.bias"], t0, Rt, 64, K)
+            t = self.new(Rt, 64)
+            L.prelu_fwd(t0, P[ig + "activation.weight"], t, Rt * 64)
+            pos = self.new(Rt, 64)
+            L.pe_dropout(P[ig + "pe.pe"], pos, B, 26, *cfg("pe"))
+            # encoder layer (input doubled, model/transformer_v2.py:273)
+            e = tr + "encoder.layers.0."
+            src2, qk = self.new(Rt, 64), self.new(Rt, 64)
+            L.axpby(t, 2.0, None, 0.0, src2, Rt * 64, 0)
+            L.axpby(src2, 1.0, pos, 1.0, qk, Rt * 64, 0)
+            a_e, att_e = self.mha_fwd(e + "self_attn.", qk, qk, src2, B, 26, cfg("enc_attn"))
+            s1, v1e = self.ln_fwd(e + "norm1.", src2, a_e, cfg("enc_drop1"), Rt)
+            f_e, ffn_e = self.ffn_fwd(e, s1, Rt, cfg("enc_ffn"))
+            mem, v2e = self.ln_fwd(e + "norm2.", s1, f_e, cfg("enc_drop2"), Rt)
+            kin = self.new(Rt, 64)
+            L.axpby(mem, 1.0, pos, 1.0, kin, Rt * 64, 0)
+
         # ---- STN head + TPS rectification (model/tsrn.py:655-657) ------------------------------------------
         if use_stn:
             xn = self.new(R0, 4)
@@ -557,29 +591,8 @@ class Engine:
         ctx["c1"], ctx["b1"] = c1, b1
 
         # ---- TP interpreter (model/tsrn.py:194-226, model/transformer_v2.py:198-244) -----------------------------------
-        Rt = B * 26
-        tpr = self.new(Rt, K)
-        if tp_ready is not None:
-            torch.cuda.current_stream().wait_event(tp_ready)
-        L.tp_rows(text_emb, text_emb.stride(0), text_emb.stride(1), text_emb.stride(3), tpr, B, K, 26)
-        t0 = self.new(Rt, 64)
-        self.linear(tpr, P[ig + "fc_in.weight"], P[ig + "fc_in.bias"], t0, Rt, 64, K)
-        t = self.new(Rt, 64)
-        L.prelu_fwd(t0, P[ig + "activation.weight"], t, Rt * 64)
-        pos = self.new(Rt, 64)
-        L.pe_dropout(P[ig + "pe.pe"], pos, B, 26, *cfg("pe"))
-        # encoder layer (input doubled, model/transformer_v2.py:273)
-        e = tr + "encoder.layers.0."
-        src2, qk = self.new(Rt, 64), self.new(Rt, 64)
-        L.axpby(t, 2.0, None, 0.0, src2, Rt * 64, 0)
-        L.axpby(src2, 1.0, pos, 1.0, qk, Rt * 64, 0)
-        a_e, att_e = self.mha_fwd(e + "self_attn.", qk, qk, src2, B, 26, cfg("enc_attn"))
-        s1, v1e = self.ln_fwd(e + "norm1.", src2, a_e, cfg("enc_drop1"), Rt)
-        f_e, ffn_e = self.ffn_fwd(e, s1, Rt, cfg("enc_ffn"))
-        mem, v2e = self.ln_fwd(e + "norm2.", s1, f_e, cfg("enc_drop2"), Rt)
-        kin = self.new(Rt, 64)
-        L.axpby(mem, 1.0, pos, 1.0, kin, Rt * 64, 0)
         # decoder layers (cross attention only, model/transformer_v2.py:805-832)
+        main.wait_stream(enc)                                                 # join the text branch: memory / keys
         main.wait_stream(side)                                                # join the RPE chain: query_pos is needed now
         tgt = b1
         dec = []
