@@ -45,3 +45,37 @@ def test_group_matches_fp64_and_single(R):
         one = torch.ones(M, N + 3, device="cuda")
         L.tn_small(dy, lddy, x, ldx, one, N + 3, None, M, N, Rp, ws)
         assert rel_l2(one[:, :N].cpu().double().numpy(), dW[:, :N].cpu().double().numpy()) < 5e-6
+
+
+def test_multi_copy_and_grouped_weight_pack():
+    """tatt_multi_copy (stacked BiGRU input weights) and tatt_conv_pack_w_group against torch indexing and tatt_conv_pack_w."""
+    from tatt_amd.lib import lib
+    L = lib()
+    srcs = [rnd(96, 64, seed=i).cuda() for i in range(5)] + [rnd(7, seed=9).cuda(), rnd(1, seed=10).cuda()]
+    lens = [t.numel() for t in srcs]
+    offs = [0]
+    for n in lens[:-1]:
+        offs.append(offs[-1] + n + 3)                       # gaps stay untouched
+    dst = torch.full((offs[-1] + lens[-1] + 5,), -7.0, device="cuda")
+    n = len(srcs)
+    L.multi_copy(n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs]), (ctypes.c_long * n)(*offs), (ctypes.c_long * n)(*lens), dst)
+    want = torch.full_like(dst, -7.0)
+    for t, o in zip(srcs, offs):
+        want[o:o + t.numel()] = t.reshape(-1)
+    assert torch.equal(dst, want)
+    shapes = [(64, 64, 3), (256, 64, 3), (32, 4, 3), (64, 4, 9), (5, 7, 1)]
+    Ws = [rnd(co, ci, k, k, seed=20 + i).cuda() for i, (co, ci, k) in enumerate(shapes)]
+    f1 = [torch.empty(w.numel(), device="cuda") for w in Ws]
+    d1 = [torch.empty(w.numel(), device="cuda") for w in Ws]
+    f2 = [torch.empty(w.numel(), device="cuda") for w in Ws]
+    d2 = [torch.empty(w.numel(), device="cuda") for w in Ws]
+    for w, a, b, (co, ci, k) in zip(Ws, f1, d1, shapes):
+        L.conv_pack_w(w, a, b, co, ci, k, k)
+    n = len(Ws)
+    VP, IN = ctypes.c_void_p * n, ctypes.c_int * n
+    L.conv_pack_w_group(n, VP(*[w.data_ptr() for w in Ws]), VP(*[t.data_ptr() for t in f2]), VP(*[t.data_ptr() for t in d2]),
+                        IN(*[s[0] for s in shapes]), IN(*[s[1] for s in shapes]), IN(*[s[2] * s[2] for s in shapes]))
+    for i, (w, (co, ci, k)) in enumerate(zip(Ws, shapes)):
+        assert torch.equal(f1[i], f2[i]) and torch.equal(d1[i], d2[i]), i
+        assert torch.equal(f2[i].view(co, k * k, ci), w.reshape(co, ci, k * k).permute(0, 2, 1))
+        assert torch.equal(d2[i].view(ci, k * k, co), w.reshape(co, ci, k * k).flip(2).permute(1, 2, 0))
