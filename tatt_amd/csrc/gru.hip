@@ -10,6 +10,7 @@
 namespace {
 
 constexpr int HID = 32;
+typedef float f32x2 __attribute__((ext_vector_type(2)));  // pairs of k: the dot products run as v_pk_fma_f32 (two FMAs per lane and issue)
 
 struct SeqMap {  // pixel index of (sequence s, step t) = (s / inner) * outer_stride + (s % inner) * inner_stride + t * tstride
   int inner;
@@ -35,12 +36,12 @@ __global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, c
   const int s = wi >> 1, dir = wi & 1;
   const float* whh = dir ? whh_b : whh_f;
   const float* bhh = dir ? bhh_b : bhh_f;
-  float wr[HID], wz[HID], wn[HID];
+  f32x2 wr[HID / 2], wz[HID / 2], wn[HID / 2];
 #pragma unroll
-  for (int k = 0; k < HID; ++k) {
-    wr[k] = whh[(0 * HID + j) * HID + k];
-    wz[k] = whh[(1 * HID + j) * HID + k];
-    wn[k] = whh[(2 * HID + j) * HID + k];
+  for (int k = 0; k < HID / 2; ++k) {
+    wr[k] = *reinterpret_cast<const f32x2*>(&whh[(0 * HID + j) * HID + 2 * k]);
+    wz[k] = *reinterpret_cast<const f32x2*>(&whh[(1 * HID + j) * HID + 2 * k]);
+    wn[k] = *reinterpret_cast<const f32x2*>(&whh[(2 * HID + j) * HID + 2 * k]);
   }
   const float br = bhh[j], bz = bhh[HID + j], bn = bhh[2 * HID + j];
   const long base = seq_base(sm, s);
@@ -72,14 +73,19 @@ __global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, c
     if (t0 + u >= T) break;
     const float g_r = c_r[u], g_z = c_z[u], g_n = c_n[u];
     __builtin_amdgcn_wave_barrier();
-    float ar = br, az = bz, an = bn;
+    f32x2 ar2 = {br, 0.f}, az2 = {bz, 0.f}, an2 = {bn, 0.f};
 #pragma unroll
     for (int k4 = 0; k4 < HID / 4; ++k4) {
-      float4 hv = *reinterpret_cast<const float4*>(&hbuf[slot][k4 * 4]);
-      ar += wr[k4 * 4] * hv.x + wr[k4 * 4 + 1] * hv.y + wr[k4 * 4 + 2] * hv.z + wr[k4 * 4 + 3] * hv.w;
-      az += wz[k4 * 4] * hv.x + wz[k4 * 4 + 1] * hv.y + wz[k4 * 4 + 2] * hv.z + wz[k4 * 4 + 3] * hv.w;
-      an += wn[k4 * 4] * hv.x + wn[k4 * 4 + 1] * hv.y + wn[k4 * 4 + 2] * hv.z + wn[k4 * 4 + 3] * hv.w;
+      const float4 hv = *reinterpret_cast<const float4*>(&hbuf[slot][k4 * 4]);
+      const f32x2 h0 = {hv.x, hv.y}, h1 = {hv.z, hv.w};
+      ar2 = __builtin_elementwise_fma(wr[2 * k4], h0, ar2);
+      az2 = __builtin_elementwise_fma(wz[2 * k4], h0, az2);
+      an2 = __builtin_elementwise_fma(wn[2 * k4], h0, an2);
+      ar2 = __builtin_elementwise_fma(wr[2 * k4 + 1], h1, ar2);
+      az2 = __builtin_elementwise_fma(wz[2 * k4 + 1], h1, az2);
+      an2 = __builtin_elementwise_fma(wn[2 * k4 + 1], h1, an2);
     }
+    const float ar = ar2.x + ar2.y, az = az2.x + az2.y, an = an2.x + an2.y;
     float r = sigmoidf_(g_r + ar), z = sigmoidf_(g_z + az);
     float n = tanhf_(g_n + r * an);
     h = (1.f - z) * n + z * h;
@@ -119,9 +125,9 @@ __global__ __launch_bounds__(256) void gru32_bwd(const float* __restrict__ dout,
   if (!active) wi = nseq * 2 - 1;
   const int s = wi >> 1, dir = wi & 1;
   const float* whh = dir ? whh_b : whh_f;
-  float wc[3 * HID];  // column j of W_hh
+  f32x2 wc[3 * HID / 2];  // column j of W_hh
 #pragma unroll
-  for (int i = 0; i < 3 * HID; ++i) wc[i] = whh[i * HID + j];
+  for (int i = 0; i < 3 * HID / 2; ++i) wc[i] = f32x2{whh[2 * i * HID + j], whh[(2 * i + 1) * HID + j]};
   const long base = seq_base(sm, s);
   const int T = sm.T;
   // forward order for dir 0 is t=0..T-1, so BPTT visits T-1..0; for dir 1 the reverse.
@@ -170,13 +176,14 @@ __global__ __launch_bounds__(256) void gru32_bwd(const float* __restrict__ dout,
       hprev_out[pix * 64 + dir * HID + j] = hp;
     }
     __builtin_amdgcn_wave_barrier();
-    float acc = d * z;
+    f32x2 a0 = {d * z, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
     for (int i4 = 0; i4 < 3 * HID / 4; ++i4) {
-      float4 gv = *reinterpret_cast<const float4*>(&gbuf[slot][i4 * 4]);
-      acc += wc[i4 * 4] * gv.x + wc[i4 * 4 + 1] * gv.y + wc[i4 * 4 + 2] * gv.z + wc[i4 * 4 + 3] * gv.w;
+      const float4 gv = *reinterpret_cast<const float4*>(&gbuf[slot][i4 * 4]);
+      a0 = __builtin_elementwise_fma(wc[2 * i4], f32x2{gv.x, gv.y}, a0);
+      a1 = __builtin_elementwise_fma(wc[2 * i4 + 1], f32x2{gv.z, gv.w}, a1);
     }
-    dh = acc;
+    dh = (a0.x + a1.x) + (a0.y + a1.y);
     pix += pstep;
     }
 #pragma unroll
