@@ -52,6 +52,34 @@ def test_gemm_nt_bias_relu_acc(M, N, K):
     close(out2, torch.relu(ref + C0.double()), what="nt+acc+relu")
 
 
+@pytest.mark.parametrize("M", [1024, 4099, 65536])
+@pytest.mark.parametrize("N,K", [(64, 64), (192, 64), (64, 192)])
+def test_gemm_tall_narrow_shapes(M, N, K):
+    """The tall K,N in {64,192} linears of the SRBs / TP decoder as the engine issues them: NT and NN forms, bias / relu /
+    accumulate, leading dimensions wider than the payload (ldw=128 halves of a stacked weight, ldc=192 slices), ragged M."""
+    A, bias, C0 = rnd(M, K), rnd(N, seed=2), rnd(M, N, seed=3)
+    Wb = rnd(N, 2 * K, seed=1)                      # the operand is the right half of a [N, 2K] matrix (ldw = 2K)
+    W = Wb[:, K:]
+    ref = A.double() @ W.double().t() + bias.double()
+    out = torch.empty(M, N, device="cuda")
+    L().gemm(cu(A), cu(Wb)[:, K:], out, cu(bias), M, N, K, K, 1, 2 * K, 1, N, 1, 0, 0, 0, 0, 0, 1, None)
+    close(out, ref, what="nt")
+    out2 = cu(C0)
+    L().gemm(cu(A), cu(Wb)[:, K:], out2, cu(bias), M, N, K, K, 1, 2 * K, 1, N, 1, 0, 0, 0, 1, 1, 1, None)
+    close(out2, torch.relu(ref) + C0.double(), what="nt+relu+acc")
+    # wide destination and source rows: C is columns [N, 2N) of a [M, 3N] buffer, A is columns [K, 2K) of [M, 2K]
+    Ab, Cb = rnd(M, 2 * K, seed=4), torch.full((M, 3 * N), 7.0, device="cuda")
+    Ad = cu(Ab)
+    L().gemm(Ad[:, K:], cu(W).contiguous(), Cb[:, N:], None, M, N, K, 2 * K, 1, K, 1, 3 * N, 1, 0, 0, 0, 0, 0, 1, None)
+    close(Cb[:, N:2 * N], Ab[:, K:].double() @ W.double().t(), what="nt wide")
+    assert (Cb[:, :N] == 7).all() and (Cb[:, 2 * N:] == 7).all()
+    # NN: dx[M,N] = dy[M,K] @ V[K,N]  (B strides sbn=1, sbk=ldv)
+    V = rnd(K, N, seed=5)
+    dx = cu(C0)
+    L().gemm(cu(A), cu(V), dx, None, M, N, K, K, 1, 1, N, N, 1, 0, 0, 0, 1, 0, 1, None)
+    close(dx, C0.double() + A.double() @ V.double(), what="nn+acc")
+
+
 def test_gemm_nn_tn_splitk_batched():
     R_, N, K = 4100, 96, 64
     dy, W, x = rnd(R_, N), rnd(N, K, seed=1), rnd(R_, K, seed=2)

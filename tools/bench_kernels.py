@@ -54,6 +54,9 @@ W64, W192, o192 = rnd(64, 64), rnd(192, 64), rnd(R, 192)
 t("gemm NT [R,64]x[64,64]", lambda: L.gemm(x64, W64, y64, b64, R, 64, 64, 64, 1, 64, 1, 64, 1, 0, 0, 0, 0, 0, 1, None), 2 * R * 64 * 64, R * 512)
 t("gemm NT [R,64]x[96,64] ldc192", lambda: L.gemm(x64, W192, o192, None, R, 96, 64, 64, 1, 64, 1, 192, 1, 0, 0, 0, 0, 0, 1, None), 2 * R * 96 * 64, R * 640)
 t("gemm NN dx [R,64]x[64,64]", lambda: L.gemm(x64, W64, y64, None, R, 64, 64, 64, 1, 1, 64, 64, 1, 0, 0, 0, 0, 0, 1, None), 2 * R * 64 * 64, R * 512)
+t("gemm NT [R,64]x[192,64]", lambda: L.gemm(x64, W192, o192, None, R, 192, 64, 64, 1, 64, 1, 192, 1, 0, 0, 0, 0, 0, 1, None), 2 * R * 192 * 64, R * 1024)
+t("gemm NN dx [R,192]x[192,64]", lambda: L.gemm(o192, W192, y64, None, R, 64, 192, 192, 1, 1, 64, 64, 1, 0, 0, 0, 0, 0, 1, None), 2 * R * 192 * 64, R * 1024)
+t("gemm NT [R,64]x[64,64] acc", lambda: L.gemm(x64, W64, y64, b64, R, 64, 64, 64, 1, 64, 1, 64, 1, 0, 0, 0, 1, 0, 1, None), 2 * R * 64 * 64, R * 768)
 t("gemm NN dx [R,96(ld192)]x[96,64]", lambda: L.gemm(o192, W192, y64, None, R, 64, 96, 192, 1, 1, 64, 64, 1, 0, 0, 0, 0, 0, 1, None), 2 * R * 96 * 64, R * 640)
 dW = rnd(64, 64)
 for sk in (64, 128, 256, 512):
