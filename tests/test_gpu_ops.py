@@ -66,7 +66,7 @@ def test_gemm_tall_narrow_shapes(M, N, K):
     close(out, ref, what="nt")
     out2 = cu(C0)
     L().gemm(cu(A), cu(Wb)[:, K:], out2, cu(bias), M, N, K, K, 1, 2 * K, 1, N, 1, 0, 0, 0, 1, 1, 1, None)
-    close(out2, torch.relu(ref) + C0.double(), what="nt+relu+acc")
+    close(out2, torch.relu(ref + C0.double()), what="nt+acc+relu")
     # wide destination and source rows: C is columns [N, 2N) of a [M, 3N] buffer, A is columns [K, 2K) of [M, 2K]
     Ab, Cb = rnd(M, 2 * K, seed=4), torch.full((M, 3 * N), 7.0, device="cuda")
     Ad = cu(Ab)
