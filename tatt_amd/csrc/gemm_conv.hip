@@ -10,6 +10,7 @@
 // The k order inside an 8-wide k-group is permuted identically for A and B (lane half h takes k = 4h+e),
 // which lets k-contiguous operands be read as one b128 per 4 MFMAs.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -135,9 +136,16 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   return *reinterpret_cast<unsigned*>(&r);
 }
 
-template <int AOP, int BOP, bool FAST, bool BF16 = false>
+//
+// TAP9 (FAST, OP_IM2COL x OP_CONVW_P only): the 3x3, Cin = 64 convolutions of the SRBs - the roofline kernel.  K = 576 is
+// exactly 18 tiles, two per tap, so the main loop is unrolled over the taps: each thread computes its 9 x 2 im2col byte
+// offsets (or the out-of-range offset where the tap falls off the image) once, in registers, and every later load is a
+// buffer_load with a register voffset and an immediate offset - no per-tile bounds tests, selects or scalar tile
+// bookkeeping, which otherwise cost MFMA issue slots 18 times per launch.
+template <int AOP, int BOP, bool FAST, bool BF16 = false, bool TAP9 = false>
 __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   static_assert(FAST || !BF16, "the bf16 path exists for the FAST loaders only");
+  static_assert(!TAP9 || (FAST && AOP == OP_IM2COL && BOP == OP_CONVW_P), "TAP9 is the 3x3 Cin=64 im2col specialisation");
   __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -502,6 +510,42 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   // tile t+1 sits in register set (t+1)&1, tile t+2 in set t&1
   // tiles 0 and 1 are requested back to back (two register sets), tile 2 as soon as tile 0 has been parked in LDS: the
   // short-K launches (K = 64..192: two to six tiles) are one memory latency shorter than with "load, store, load, load"
+  if constexpr (TAP9) {
+    int va[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const int delta = ((dy * a.g.W + dx) * a.g.ldx) * 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool ok = (unsigned)(a_py[j] + dy) < (unsigned)a.g.H && (unsigned)(a_px[j] + dx) < (unsigned)a.g.W;
+        va[tap][j] = ok ? fa_vo[j] + delta : BUF_OOB;
+      }
+    }
+    auto load_tap = [&](int tile, float4 (&ra)[2], float4& rb) {  // tile is a constant after unrolling: tap = tile / 2, ci half = tile % 2
+      if (tile >= 18) return;
+      const int tap = tile >> 1, half = tile & 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ra[j] = bload4s(rsrcA, va[tap][j], half * (BK * 4));
+      rb = bload4s(rsrcB, fb_vo, (tap * 64 + half * BK) * 4);
+    };
+    load_tap(0, ra0, rb0);
+    load_tap(1, ra1, rb1);
+    store_tiles(0, ra0, rb0);
+    load_tap(2, ra0, rb0);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 18; t += 2) {
+      store_tiles(1, ra1, rb1);
+      load_tap(t + 3, ra1, rb1);
+      compute(0);
+      __syncthreads();
+      if (t + 2 < 18) store_tiles(0, ra0, rb0);
+      load_tap(t + 4, ra0, rb0);
+      compute(1);
+      if (t + 2 < 18) __syncthreads();
+    }
+  } else {
   load_tiles(kbeg, ra0, rb0);
   load_tiles(kbeg + BK, ra1, rb1);
   store_tiles(0, ra0, rb0);
@@ -519,6 +563,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
     load_tiles(kbeg + (t + 4) * BK, ra0, rb0);
     compute(1);
     __syncthreads();
+  }
   }
 
   // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ------------------
@@ -681,10 +726,19 @@ bool fast_ok(const GemmArgs& a) {
 }
 
 int g_matmul_bf16 = 0;  // tatt_set_matmul_precision
+const int g_tap9 = [] { const char* e = getenv("TATT_CONV_TAP9"); return (e && e[0] == '0') ? 0 : 1; }();  // =0: generic loop (A/B runs)
 
 template <int AOP, int BOP>
 int launch(const GemmArgs& a, int batch, hipStream_t st) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch * a.splitk);
+  if constexpr (AOP == OP_IM2COL && BOP == OP_CONVW_P) {  // 3x3, Cin = 64, packed weights, whole K in one pass: tap-unrolled loop
+    if (g_tap9 && fast_ok<AOP, BOP>(a) && a.g.Cin == 64 && a.g.KH == 3 && a.g.KW == 3 && a.splitk == 1 && a.K == 576 && a.w_stap == 64) {
+      if (g_matmul_bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, true>), grid, dim3(NTHR), 0, st, a);
+      else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, false, true>), grid, dim3(NTHR), 0, st, a);
+      TATT_LAUNCH_CHECK("gemm_kernel<tap9>");
+      return TATT_OK;
+    }
+  }
   if (fast_ok<AOP, BOP>(a)) {
     if (g_matmul_bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true>), grid, dim3(NTHR), 0, st, a);
     else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true>), grid, dim3(NTHR), 0, st, a);
