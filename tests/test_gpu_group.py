@@ -79,3 +79,42 @@ def test_multi_copy_and_grouped_weight_pack():
         assert torch.equal(f1[i], f2[i]) and torch.equal(d1[i], d2[i]), i
         assert torch.equal(f2[i].view(co, k * k, ci), w.reshape(co, ci, k * k).permute(0, 2, 1))
         assert torch.equal(d2[i].view(ci, k * k, co), w.reshape(co, ci, k * k).flip(2).permute(1, 2, 0))
+
+
+def test_conv_tap_unrolled_loop_is_bit_identical_to_generic_loop():
+    """The tap-unrolled K loop of the 3x3 Cin=64 convolutions (TAP9) adds the same products in the same order as the generic
+    loop: the outputs of forward and input-gradient launches must agree bit for bit (TATT_CONV_TAP9=0 selects the generic loop
+    when the library is loaded, hence the two child processes)."""
+    import hashlib, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+from tatt_amd.lib import lib
+L = lib(); B, H, W = 5, 16, 64; R = B * H * W
+g = torch.Generator().manual_seed(3)
+x, w, b = [torch.randn(*s, generator=g).cuda() for s in ((R, 64), (64, 64, 3, 3), (64,))]
+w256 = torch.randn(256, 64, 3, 3, generator=g).cuda()
+wf, wd = torch.empty(64 * 576, device="cuda"), torch.empty(64 * 576, device="cuda")
+L.conv_pack_w(w, wf, wd, 64, 64, 3, 3)
+wf2, wd2 = torch.empty(256 * 576, device="cuda"), torch.empty(256 * 576, device="cuda")
+L.conv_pack_w(w256, wf2, wd2, 256, 64, 3, 3)
+y, dx, y2 = torch.empty(R, 64, device="cuda"), torch.empty(R, 64, device="cuda"), torch.empty(R, 256, device="cuda")
+L.conv_fwd(x, wf, b, y, B, H, W, 64, 64, 3, 3, 64, 64, 576, 1, 0, 64, 0, 1)      # packed forward, relu
+L.conv_fwd(y, wd, None, dx, B, H, W, 64, 64, 3, 3, 64, 64, 576, 1, 0, 64, 0, 0)  # packed dgrad weights
+L.conv_fwd(x, wf2, None, y2, B, H, W, 64, 256, 3, 3, 64, 256, 576, 1, 0, 64, 0, 0)
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for t in (y, dx, y2):
+    h.update(t.cpu().numpy().tobytes())
+print("HASH", h.hexdigest(), float(y.abs().sum()), float(y2.abs().sum()))
+''' % root
+    out = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, TATT_CONV_TAP9=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0].split()
+        assert float(line[2]) > 0 and float(line[3]) > 0
+        out[mode] = line[1]
+    assert out["0"] == out["1"]
