@@ -144,6 +144,28 @@ def test_conv_fwd_dgrad_wgrad(B, H, W, Cin, Cout, k):
     close(db, b.grad, what="dbias")
 
 
+@pytest.mark.parametrize("B,H,W,sk", [(3, 16, 64, 7), (64, 16, 64, 256), (1, 5, 6, 3), (2, 3, 2, 1), (1, 1, 2, 5), (5, 16, 64, 1000)])
+def test_conv3x3_wgrad_borders_and_slices(B, H, W, sk):
+    """3x3, 64 -> 64 weight gradient (the SRB shape): image borders for every tap, split counts that do not divide the pixel
+    count, accumulate on and off, operands that are column slices of wider NHWC buffers."""
+    Cin = Cout = 64
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x.double(), w, padding=1).backward(dy.double())
+    xb = torch.full((B, H, W, 2 * Cin), 5.0)                      # operands are column slices of wider NHWC buffers
+    xb[..., Cin:] = x.permute(0, 2, 3, 1)
+    dyb = torch.full((B, H, W, 3 * Cout), -3.0)
+    dyb[..., Cout:2 * Cout] = dy.permute(0, 2, 3, 1)
+    xn, dyn = cu(xb), cu(dyb)
+    dW = torch.full((Cout, Cin, 3, 3), 2.0, device="cuda")
+    L().conv_wgrad(xn.view(-1, 2 * Cin)[:, Cin:], dyn.view(-1, 3 * Cout)[:, Cout:], dW, B, H, W, Cin, Cout, 3, 3, 2 * Cin, 3 * Cout, sk, ws(48 << 20), 1)
+    close(dW, w.grad + 2.0, what="accumulate")
+    L().conv_wgrad(xn.view(-1, 2 * Cin)[:, Cin:], dyn.view(-1, 3 * Cout)[:, Cout:], dW, B, H, W, Cin, Cout, 3, 3, 2 * Cin, 3 * Cout, sk, ws(48 << 20), 0)
+    close(dW, w.grad, what="overwrite")
+
+
 @pytest.mark.parametrize("B,H,W,Cbig,Csmall,k", [(2, 32, 128, 64, 4, 9), (3, 16, 64, 64, 4, 9), (2, 8, 8, 32, 8, 3), (1, 5, 7, 64, 16, 3)])
 def test_conv_skinny_fwd_and_dgrad(B, H, W, Cbig, Csmall, k):
     """Skinny-Cout path: forward Cbig->Csmall, and the dgrad of a Csmall->Cbig conv (model/tsrn.py:625, :598)."""
