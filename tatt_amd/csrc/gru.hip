@@ -354,10 +354,12 @@ __global__ void rpe_whh_transpose(const float* __restrict__ whh_f, const float* 
   for (int r = ty; r < 32; r += 8) O[(long)(jb + r) * 3 * RH + i0 + tx] = t[tx][r];
 }
 
-// backward step s: block (jb, mh, dir) owns rows mh*32..+31, units jb*16..+15.  First the recurrent gradient arriving from
+// backward step s: block (jb, mh, dir) owns rows mh*16*MT..+16*MT-1, units jb*16..+15 (MT = 1: 256 workgroups, one per CU; with
+// MT = 2 the 128 workgroups left half of the CUs idle and each wave had twice the MFMA chain).  First the recurrent gradient arriving from
 // step s+1, carry = d_{s+1} z_{s+1} (left in `carry` by that step) + dgh_{s+1} W_hh (K = 1536 split over the four waves,
 // three 128-wide chunks each), then the gate backward of step s for the same (row, unit) elements.  dgh_next == nullptr
 // for the first (last-in-time) step.
+template <int MT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rpe_step_bwd(const float* __restrict__ gi, const float* __restrict__ gh,
                                                     const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
                                                     const float* __restrict__ hprev, const float* __restrict__ dqp,
@@ -365,32 +367,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                     float* __restrict__ dgh_out, float* __restrict__ dgi_sum,
                                                     const float* __restrict__ whhT, int s, int B, long dir_stride_gh,
                                                     long dir_stride_h) {
-  __shared__ float red[4][32][17];
+  constexpr int RM = 16 * MT;  // rows per workgroup
+  __shared__ float red[4][RM][17];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, q = lane >> 4;
   const int jb = blockIdx.x, mh = blockIdx.y, dir = blockIdx.z;
   if (dgh_next) {
-    const float* A = dgh_next + dir * dir_stride_gh + (long)(mh * 32 + i) * 3 * RH + wv * 384 + q * 4;
+    const float* A = dgh_next + dir * dir_stride_gh + (long)(mh * RM + i) * 3 * RH + wv * 384 + q * 4;
     const float* Bt = whhT + ((long)dir * RH + jb * 16 + i) * 3 * RH + wv * 384 + q * 4;
-    float4 af[3][2][8], bf[3][8];
+    float4 af[3][MT][8], bf[3][8];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {  // issued in the order the MFMAs consume them
         bf[c][e] = *reinterpret_cast<const float4*>(Bt + c * 128 + 16 * e);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) af[c][mt][e] = *reinterpret_cast<const float4*>(A + (long)mt * 16 * 3 * RH + c * 128 + 16 * e);
+        for (int mt = 0; mt < MT; ++mt) af[c][mt][e] = *reinterpret_cast<const float4*>(A + (long)mt * 16 * 3 * RH + c * 128 + 16 * e);
       }
     }
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    __builtin_amdgcn_sched_barrier(0);  // all 72 loads in flight before the first MFMA: the step is pure latency
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);  // every load in flight before the first MFMA: the step is pure latency
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int e = 0; e < 8; ++e)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) mfma4(acc[mt], af[c][mt][e], bf[c][e]);
+        for (int mt = 0; mt < MT; ++mt) mfma4(acc[mt], af[c][mt][e], bf[c][e]);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wv][mt * 16 + 4 * q + r][i] = acc[mt][r];
   }
@@ -398,9 +403,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const float* bh = dir ? bhh_b : bhh_f;
   const int tt = dir ? B - 1 - s : s;
 #pragma unroll
-  for (int h2 = 0; h2 < 2; ++h2) {
+  for (int h2 = 0; h2 < MT; ++h2) {
     const int e = tid + 256 * h2, wl = e >> 4, jj = e & 15;
-    const int w = mh * 32 + wl, j = jb * 16 + jj;
+    const int w = mh * RM + wl, j = jb * 16 + jj;
     const long ci = ((long)dir * RW + w) * RH + j;
     float c = carry[ci];
     if (dgh_next) c += (red[0][wl][jj] + red[1][wl][jj]) + (red[2][wl][jj] + red[3][wl][jj]);
@@ -452,7 +457,7 @@ int tatt_rpe_step_bwd(const float* gi, const float* gh, const float* bhh_f, cons
                       const float* dqp, float* carry, const float* dgh_next, float* dgh_out, float* dgi_sum, const float* whhT,
                       int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t st) {
   TATT_CHECK_ARG(gi && gh && hprev && dqp && carry && dgh_out && dgi_sum && whhT && s >= 0 && s < B, "tatt_rpe_step_bwd: bad arguments");
-  hipLaunchKernelGGL(rpe_step_bwd, dim3(RH / 16, 2, 2), dim3(256), 0, st, gi, gh, bhh_f, bhh_b, hprev, dqp, carry, dgh_next, dgh_out,
+  hipLaunchKernelGGL(rpe_step_bwd<1>, dim3(RH / 16, RW / 16, 2), dim3(256), 0, st, gi, gh, bhh_f, bhh_b, hprev, dqp, carry, dgh_next, dgh_out,
                      dgi_sum, whhT, s, B, dir_stride_gh, dir_stride_h);
   TATT_LAUNCH_CHECK("rpe_step_bwd");
   return TATT_OK;
