@@ -282,32 +282,35 @@ __device__ __forceinline__ void mfma4(f32x4& acc, const float4& a, const float4&
 }
 
 // forward step: block (jb, dir) owns hidden units j0..j0+3 (12 gate columns, padded to one 16-wide tile) for all 64 rows;
-// the four waves split K = 512.  Writes h_{s+1}, query_pos and the raw gh (no bias) that the backward pass re-reads.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rpe_step_fwd(const float* __restrict__ gi, const float* __restrict__ whh_f,
+// the NWV waves split K = 512 (eight: half the MFMA chain and half the loads per wave of four).  Writes h_{s+1}, query_pos and the raw gh (no bias) that the backward pass re-reads.
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void rpe_step_fwd(const float* __restrict__ gi, const float* __restrict__ whh_f,
                                                     const float* __restrict__ whh_b, const float* __restrict__ bhh_f,
                                                     const float* __restrict__ bhh_b, const float* __restrict__ hprev,
                                                     float* __restrict__ hout, float* __restrict__ gh_out, float* __restrict__ qp,
                                                     int s, int B, long dir_stride_gh, long dir_stride_h) {
-  __shared__ float red[4][RW][17];
+  constexpr int NE = RH / NWV / 16;  // float4 k-steps per wave
+  __shared__ float red[NWV][RW][17];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, q = lane >> 4;
   const int dir = blockIdx.y, j0 = blockIdx.x * 4;
   const float* W = dir ? whh_b : whh_f;
   const float* hp = hprev + dir * dir_stride_h;
-  const int kbase = wv * 128 + q * 4;  // step e: k = kbase + 16e (+c): the 4 q-lanes of a row read one 64-byte line
-  float4 bf[8], af[4][8];
+  const int kbase = wv * (RH / NWV) + q * 4;  // step e: k = kbase + 16e (+c): the 4 q-lanes of a row read one 64-byte line
+  float4 bf[NE], af[4][NE];
   {
     const bool on = i < 12;
     const float* pb = W + (long)((i >> 2) * RH + j0 + (i & 3)) * RH + kbase;
     const float* pa = hp + (long)i * RH + kbase;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {  // issued in the order the MFMAs consume them
+    for (int e = 0; e < NE; ++e) {  // issued in the order the MFMAs consume them
       bf[e] = on ? *reinterpret_cast<const float4*>(pb + 16 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) af[mt][e] = *reinterpret_cast<const float4*>(pa + (long)mt * 16 * RH + 16 * e);
     }
   }
   // gate operands of this thread's (row, unit): issued before the MFMAs so that their latency hides behind them
-  const int w = tid >> 2, jj = tid & 3, j = j0 + jj;
+  const int gt = tid & 255;  // gate element of this thread (threads 256.. of an 8-wave block only take part in the product)
+  const int w = gt >> 2, jj = gt & 3, j = j0 + jj;
   const float* g_i = gi + ((long)dir * RW + w) * 3 * RH;
   const float* bh = dir ? bhh_b : bhh_f;
   const float gir = g_i[j], giz = g_i[RH + j], gin = g_i[2 * RH + j];
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   __builtin_amdgcn_sched_barrier(0);  // every load above is issued before the first MFMA: the step is pure latency
 #pragma unroll
-  for (int e = 0; e < 8; ++e)
+  for (int e = 0; e < NE; ++e)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) mfma4(acc[mt], af[mt][e], bf[e]);
 #pragma unroll
@@ -326,9 +329,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wv][mt * 16 + 4 * q + r][i] = acc[mt][r];
   __syncthreads();
+  if (tid >= 256) return;
   float gh[3];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) gh[g] = (red[0][w][g * 4 + jj] + red[1][w][g * 4 + jj]) + (red[2][w][g * 4 + jj] + red[3][w][g * 4 + jj]);
+  for (int g = 0; g < 3; ++g) {
+    float t = 0.f;
+#pragma unroll
+    for (int v = 0; v < NWV; v += 2) t += red[v][w][g * 4 + jj] + red[v + 1][w][g * 4 + jj];
+    gh[g] = t;
+  }
   const float r = sigmoidf_(gir + gh[0] + br);
   const float z = sigmoidf_(giz + gh[1] + bz);
   const float n = tanhf_(gin + r * (gh[2] + bn));
@@ -441,7 +450,7 @@ int tatt_rpe_step_fwd(const float* gi, const float* whh_f, const float* whh_b, c
                       const float* hprev, float* hout, float* gh_out, float* qp, int s, int B, long dir_stride_gh,
                       long dir_stride_h, hipStream_t st) {
   TATT_CHECK_ARG(gi && whh_f && whh_b && hprev && hout && gh_out && qp && s >= 0 && s < B, "tatt_rpe_step_fwd: bad arguments");
-  hipLaunchKernelGGL(rpe_step_fwd, dim3(RH / 4, 2), dim3(256), 0, st, gi, whh_f, whh_b, bhh_f, bhh_b, hprev, hout, gh_out, qp, s, B,
+  hipLaunchKernelGGL(rpe_step_fwd<8>, dim3(RH / 4, 2), dim3(512), 0, st, gi, whh_f, whh_b, bhh_f, bhh_b, hprev, hout, gh_out, qp, s, B,
                      dir_stride_gh, dir_stride_h);
   TATT_LAUNCH_CHECK("rpe_step_fwd");
   return TATT_OK;
