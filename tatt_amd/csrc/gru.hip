@@ -368,8 +368,8 @@ __global__ void rpe_whh_transpose(const float* __restrict__ whh_f, const float* 
 // step s+1, carry = d_{s+1} z_{s+1} (left in `carry` by that step) + dgh_{s+1} W_hh (K = 1536 split over the four waves,
 // three 128-wide chunks each), then the gate backward of step s for the same (row, unit) elements.  dgh_next == nullptr
 // for the first (last-in-time) step.
-template <int MT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rpe_step_bwd(const float* __restrict__ gi, const float* __restrict__ gh,
+template <int MT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void rpe_step_bwd(const float* __restrict__ gi, const float* __restrict__ gh,
                                                     const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
                                                     const float* __restrict__ hprev, const float* __restrict__ dqp,
                                                     float* __restrict__ carry, const float* __restrict__ dgh_next,
@@ -377,20 +377,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                     const float* __restrict__ whhT, int s, int B, long dir_stride_gh,
                                                     long dir_stride_h) {
   constexpr int RM = 16 * MT;  // rows per workgroup
-  __shared__ float red[4][RM][17];
+  constexpr int KW = 3 * RH / NWV, CH = KW / 3, NE = CH / 16;  // K range of a wave, in three chunks of NE float4 steps
+  __shared__ float red[NWV][RM][17];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, q = lane >> 4;
   const int jb = blockIdx.x, mh = blockIdx.y, dir = blockIdx.z;
   if (dgh_next) {
-    const float* A = dgh_next + dir * dir_stride_gh + (long)(mh * RM + i) * 3 * RH + wv * 384 + q * 4;
-    const float* Bt = whhT + ((long)dir * RH + jb * 16 + i) * 3 * RH + wv * 384 + q * 4;
-    float4 af[3][MT][8], bf[3][8];
+    const float* A = dgh_next + dir * dir_stride_gh + (long)(mh * RM + i) * 3 * RH + wv * KW + q * 4;
+    const float* Bt = whhT + ((long)dir * RH + jb * 16 + i) * 3 * RH + wv * KW + q * 4;
+    float4 af[3][MT][NE], bf[3][NE];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {  // issued in the order the MFMAs consume them
-        bf[c][e] = *reinterpret_cast<const float4*>(Bt + c * 128 + 16 * e);
+      for (int e = 0; e < NE; ++e) {  // issued in the order the MFMAs consume them
+        bf[c][e] = *reinterpret_cast<const float4*>(Bt + c * CH + 16 * e);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[c][mt][e] = *reinterpret_cast<const float4*>(A + (long)mt * 16 * 3 * RH + c * 128 + 16 * e);
+        for (int mt = 0; mt < MT; ++mt) af[c][mt][e] = *reinterpret_cast<const float4*>(A + (long)mt * 16 * 3 * RH + c * CH + 16 * e);
       }
     }
     f32x4 acc[MT];
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
+      for (int e = 0; e < NE; ++e)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) mfma4(acc[mt], af[c][mt][e], bf[c][e]);
 #pragma unroll
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int r = 0; r < 4; ++r) red[wv][mt * 16 + 4 * q + r][i] = acc[mt][r];
   }
   __syncthreads();
+  if (tid >= 256) return;  // the gate phase has 256 elements per 16 rows
   const float* bh = dir ? bhh_b : bhh_f;
   const int tt = dir ? B - 1 - s : s;
 #pragma unroll
@@ -417,7 +419,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int w = mh * RM + wl, j = jb * 16 + jj;
     const long ci = ((long)dir * RW + w) * RH + j;
     float c = carry[ci];
-    if (dgh_next) c += (red[0][wl][jj] + red[1][wl][jj]) + (red[2][wl][jj] + red[3][wl][jj]);
+    if (dgh_next) {
+#pragma unroll
+      for (int v = 0; v < NWV; v += 2) c += red[v][wl][jj] + red[v + 1][wl][jj];
+    }
     const float* g_i = gi + ((long)dir * RW + w) * 3 * RH;
     const float* g_h = gh + dir * dir_stride_gh + (long)w * 3 * RH;
     const float hp = hprev[dir * dir_stride_h + (long)w * RH + j];
@@ -466,7 +471,7 @@ int tatt_rpe_step_bwd(const float* gi, const float* gh, const float* bhh_f, cons
                       const float* dqp, float* carry, const float* dgh_next, float* dgh_out, float* dgi_sum, const float* whhT,
                       int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t st) {
   TATT_CHECK_ARG(gi && gh && hprev && dqp && carry && dgh_out && dgi_sum && whhT && s >= 0 && s < B, "tatt_rpe_step_bwd: bad arguments");
-  hipLaunchKernelGGL(rpe_step_bwd<1>, dim3(RH / 16, RW / 16, 2), dim3(256), 0, st, gi, gh, bhh_f, bhh_b, hprev, dqp, carry, dgh_next, dgh_out,
+  hipLaunchKernelGGL((rpe_step_bwd<1, 8>), dim3(RH / 16, RW / 16, 2), dim3(512), 0, st, gi, gh, bhh_f, bhh_b, hprev, dqp, carry, dgh_next, dgh_out,
                      dgi_sum, whhT, s, B, dir_stride_gh, dir_stride_h);
   TATT_LAUNCH_CHECK("rpe_step_bwd");
   return TATT_OK;
