@@ -381,6 +381,26 @@ __global__ __launch_bounds__(64 * NWV) void rpe_step_bwd(const float* __restrict
   __shared__ float red[NWV][RM][17];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, q = lane >> 4;
   const int jb = blockIdx.x, mh = blockIdx.y, dir = blockIdx.z;
+  // gate operands of this thread's (row, unit) elements: issued before the product so that their latency hides behind it
+  // (they do not depend on it); threads 256.. of the workgroup only take part in the product
+  const float* bh = dir ? bhh_b : bhh_f;
+  const int tt = dir ? B - 1 - s : s;
+  const int gt = tid & 255;
+  float g_c[MT], g_ir[MT], g_iz[MT], g_in[MT], g_hr[MT], g_hz[MT], g_hn[MT], g_hp[MT], g_dq[MT], g_br[MT], g_bz[MT], g_bn[MT];
+#pragma unroll
+  for (int h2 = 0; h2 < MT; ++h2) {
+    const int e = gt + 256 * h2, wl = e >> 4, jj = e & 15;
+    const int w = mh * RM + wl, j = jb * 16 + jj;
+    const float* g_i = gi + ((long)dir * RW + w) * 3 * RH;
+    const float* g_h = gh + dir * dir_stride_gh + (long)w * 3 * RH;
+    const int f = dir * RH + j;
+    g_c[h2] = carry[((long)dir * RW + w) * RH + j];
+    g_ir[h2] = g_i[j]; g_iz[h2] = g_i[RH + j]; g_in[h2] = g_i[2 * RH + j];
+    g_hr[h2] = g_h[j]; g_hz[h2] = g_h[RH + j]; g_hn[h2] = g_h[2 * RH + j];
+    g_br[h2] = bh[j]; g_bz[h2] = bh[RH + j]; g_bn[h2] = bh[2 * RH + j];
+    g_hp[h2] = hprev[dir * dir_stride_h + (long)w * RH + j];
+    g_dq[h2] = dqp[(((long)tt * 16 + (f >> 6)) * RW + w) * 64 + (f & 63)];
+  }
   if (dgh_next) {
     const float* A = dgh_next + dir * dir_stride_gh + (long)(mh * RM + i) * 3 * RH + wv * KW + q * 4;
     const float* Bt = whhT + ((long)dir * RH + jb * 16 + i) * 3 * RH + wv * KW + q * 4;
@@ -411,27 +431,22 @@ __global__ __launch_bounds__(64 * NWV) void rpe_step_bwd(const float* __restrict
   }
   __syncthreads();
   if (tid >= 256) return;  // the gate phase has 256 elements per 16 rows
-  const float* bh = dir ? bhh_b : bhh_f;
-  const int tt = dir ? B - 1 - s : s;
 #pragma unroll
   for (int h2 = 0; h2 < MT; ++h2) {
     const int e = tid + 256 * h2, wl = e >> 4, jj = e & 15;
     const int w = mh * RM + wl, j = jb * 16 + jj;
     const long ci = ((long)dir * RW + w) * RH + j;
-    float c = carry[ci];
+    float c = g_c[h2];
     if (dgh_next) {
 #pragma unroll
       for (int v = 0; v < NWV; v += 2) c += red[v][wl][jj] + red[v + 1][wl][jj];
     }
-    const float* g_i = gi + ((long)dir * RW + w) * 3 * RH;
-    const float* g_h = gh + dir * dir_stride_gh + (long)w * 3 * RH;
-    const float hp = hprev[dir * dir_stride_h + (long)w * RH + j];
-    const float ghn = g_h[2 * RH + j] + bh[2 * RH + j];
-    const float r = sigmoidf_(g_i[j] + g_h[j] + bh[j]);
-    const float z = sigmoidf_(g_i[RH + j] + g_h[RH + j] + bh[RH + j]);
-    const float n = tanhf_(g_i[2 * RH + j] + r * ghn);
-    const int f = dir * RH + j;
-    const float d = c + dqp[(((long)tt * 16 + (f >> 6)) * RW + w) * 64 + (f & 63)];
+    const float hp = g_hp[h2];
+    const float ghn = g_hn[h2] + g_bn[h2];
+    const float r = sigmoidf_(g_ir[h2] + g_hr[h2] + g_br[h2]);
+    const float z = sigmoidf_(g_iz[h2] + g_hz[h2] + g_bz[h2]);
+    const float n = tanhf_(g_in[h2] + r * ghn);
+    const float d = c + g_dq[h2];
     const float dn = d * (1.f - z) * (1.f - n * n);
     const float dz = d * (hp - n) * z * (1.f - z);
     const float dr = dn * ghn * r * (1.f - r);
