@@ -752,7 +752,8 @@ class Engine:
             dnext = dtgt
         axpby(dnext, 1.0, None, 0.0, db1, R0 * 64, 1)
         axpby(dkin, 1.0, None, 0.0, dmem, Rt * 64, 1)                     # kin = mem + pos
-        self._w_flush()                                                        # the decoder's weight gradients start now
+        # (no flush here: the decoder's and the encoder's weight gradients stay queued until rpe_finish() -- bulk kernels beside the
+        #  RPE chain slow its 64 latency-bound steps down by more than the overlap returns: 9.51 -> 9.45 ms)
         # recurrent positional encoding, BPTT over the batch axis: dqp is complete here.  The chain of B latency-bound
         # launches runs on the side stream beside the encoder / block1 / STN backward; its weight-gradient GEMMs (which
         # need the shared workspace) follow after the join at the end of the pass.
@@ -797,7 +798,6 @@ class Engine:
         dt0 = self.new(Rt, 64)
         L.prelu_bwd(t0, P[ig + "activation.weight"], dt, dt0, G[ig + "activation.weight"], 1, Rt * 64, self.ws)
         self.linear_dwb(dt0, tpr, G[ig + "fc_in.weight"], G[ig + "fc_in.bias"], Rt, 64, K)
-        self._w_flush()
 
         # ---- block1 ------------------------------------------------------------------------------------------------
         dc1 = self.new(R0, 64)
