@@ -590,6 +590,18 @@ class Engine:
         L.prelu_fwd(c1, P["block1.1.weight"], b1, R0 * 64)
         ctx["c1"], ctx["b1"] = c1, b1
 
+        # The first SRB's convolutions (conv-BN-mish-conv-BN, model/tsrn.py:333-338) need block1's output only: they go here,
+        # ahead of the decoder, where the main chain would otherwise sit waiting for the RPE chain's query_pos.
+        def srb_convs(pre, blk):
+            ca = self.new(R0, 64)
+            self.conv(blk, P[pre + "conv1.weight"], P[pre + "conv1.bias"], ca, B, H, W, 64, 64, 3)
+            ma, st1 = self.bn(pre + "bn1.", ca, R0, 64, training, 2)
+            cb = self.new(R0, 64)
+            self.conv(ma, P[pre + "conv2.weight"], P[pre + "conv2.bias"], cb, B, H, W, 64, 64, 3)
+            r2, st2 = self.bn(pre + "bn2.", cb, R0, 64, training, 0)
+            return ca, ma, st1, cb, r2, st2
+        first_convs = srb_convs("block2.", b1) if m.srb_nums > 0 else None
+
         # ---- TP interpreter (model/tsrn.py:194-226, model/transformer_v2.py:198-244) -----------------------------------
         # decoder layers (cross attention only, model/transformer_v2.py:805-832)
         main.wait_stream(enc)                                                 # join the text branch: memory / keys
@@ -617,12 +629,7 @@ class Engine:
         srbs = []
         for i in range(m.srb_nums):
             pre = f"block{i + 2}."
-            ca = self.new(R0, 64)
-            self.conv(blk, P[pre + "conv1.weight"], P[pre + "conv1.bias"], ca, B, H, W, 64, 64, 3)
-            ma, st1 = self.bn(pre + "bn1.", ca, R0, 64, training, 2)
-            cb = self.new(R0, 64)
-            self.conv(ma, P[pre + "conv2.weight"], P[pre + "conv2.bias"], cb, B, H, W, 64, 64, 3)
-            r2, st2 = self.bn(pre + "bn2.", cb, R0, 64, training, 0)
+            ca, ma, st1, cb, r2, st2 = first_convs if i == 0 else srb_convs(pre, blk)
             r = self.gru_block_fwd(pre + "gru1.", [(r2, 0, 64), (tp_map, 64, 64)], B, H, W, True, want_ctx, ctx, pre + "gru1")
             s = self.new(R0, 64)
             L.axpby(blk, 1.0, r, 1.0, s, R0 * 64, 0)
