@@ -38,6 +38,9 @@ class Ctx:
     def __setitem__(self, k, v):
         self.t[k] = v
 
+    def get(self, k, default=None):
+        return self.t.get(k, default)
+
 
 class Engine:
     def __init__(self, module):
@@ -464,7 +467,7 @@ class Engine:
         return dres
 
     # ================================================================================================================
-    def forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True, wpack=None, tp_ready=None):
+    def forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True, wpack=None, tp_ready=None, rpe_from=None):
         """tp_ready: optional torch.cuda.Event after which `text_emb` may be read (the prior generator may still be running on
         another stream while the STN head, block1 and the RPE chain -- which do not need the prior -- are under way).
         wpack: the packed conv weights of an earlier forward call on the SAME weights (the TSC step runs the network
@@ -498,22 +501,32 @@ class Engine:
         # run beside it (inside a captured hipGraph this becomes a parallel branch).
         ig, tr = "infoGen.", "infoGen.transformer."
         g = tr + "gru_encoding."
-        xg = self.new(64, 1024)
-        L.rpe_gather_x(P[ig + "init_factor.weight"], xg)
-        gi = self.new(2, 64, 1536)
-        self.linear(xg, P[g + "weight_ih_l0"], P[g + "bias_ih_l0"], gi[0], 64, 1536, 1024, splitk=8)
-        self.linear(xg, P[g + "weight_ih_l0_reverse"], P[g + "bias_ih_l0_reverse"], gi[1], 64, 1536, 1024, splitk=8)
-        hstep = self.zeros(2, B + 1, 64, 512)
-        gh_all = self.new(2, B, 64, 1536)
-        qp = self.new(R0, 64)
-        whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
-        dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
         main, side = torch.cuda.current_stream(), self.side_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            for s in range(B):  # one fused launch per step: h_s W_hh^T, gates, h_{s+1}, query_pos (tatt_rpe_step_fwd)
-                L.rpe_step_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], hstep[0, s + 1],
-                               gh_all[0, s], qp, s, B, dsg, dsh)
+        if rpe_from is not None:
+            # A second forward pass of the same optimisation step (the TSC term's SR pass over the rotated input): the encoding is a
+            # function of the weights alone, so the first pass's chain is reused; backward() of this pass then hands its dL/dquery_pos
+            # to that pass (ctx["rpe_owner"]) instead of running a BPTT chain of its own -- the chain is linear in that gradient.
+            if rpe_from["meta"][0] != B or rpe_from.get("rpe_owner") is not None:
+                raise RuntimeError("rpe_from must be the context of a forward pass of this step with the same batch size that ran the RPE itself")
+            xg, gi, hstep, gh_all, qp = (rpe_from["tp"][i] for i in (4, 5, 6, 7, 8))
+            ctx["rpe_owner"] = rpe_from
+            rpe_from["rpe_lent"] = True
+        else:
+            xg = self.new(64, 1024)
+            L.rpe_gather_x(P[ig + "init_factor.weight"], xg)
+            gi = self.new(2, 64, 1536)
+            self.linear(xg, P[g + "weight_ih_l0"], P[g + "bias_ih_l0"], gi[0], 64, 1536, 1024, splitk=8)
+            self.linear(xg, P[g + "weight_ih_l0_reverse"], P[g + "bias_ih_l0_reverse"], gi[1], 64, 1536, 1024, splitk=8)
+            hstep = self.zeros(2, B + 1, 64, 512)
+            gh_all = self.new(2, B, 64, 1536)
+            qp = self.new(R0, 64)
+            whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
+            dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for s in range(B):  # one fused launch per step: h_s W_hh^T, gates, h_{s+1}, query_pos (tatt_rpe_step_fwd)
+                    L.rpe_step_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], hstep[0, s + 1],
+                                   gh_all[0, s], qp, s, B, dsg, dsh)
 
         # ---- text branch of the TP interpreter (fc_in, PReLU, positional encoding, encoder layer): it reads the prior and weights
         # only, so it runs on a stream of its own beside the STN head / block1 (and the RPE chain) until the decoder needs it
@@ -772,14 +785,24 @@ class Engine:
         dgh_all = self.new(2, B, 64, 1536)
         whhT = self.new(2, 512, 1536)
         main, side = torch.cuda.current_stream(), self.side_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            L.rpe_whh_transpose(whh_f, whh_b, whhT)
-            for s in reversed(range(B)):
-                L.rpe_step_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
-                               dgh_all[0, s + 1] if s + 1 < B else None, dgh_all[0, s], dgi_sum, whhT, s, B, dsg, dsh)
+        owner = ctx.get("rpe_owner")
+        if owner is not None:                                   # the chain belongs to another pass of this step (forward(rpe_from=...))
+            owner["dqp_extra"] = dqp
+        else:
+            if ctx.get("rpe_lent"):                             # gradient handed over by the pass that reused this chain
+                if ctx.get("dqp_extra") is None:
+                    raise RuntimeError("the pass that reused this pass's RPE chain (forward(rpe_from=...)) must run its backward first")
+                axpby(ctx["dqp_extra"], 1.0, None, 0.0, dqp, R0 * 64, 1)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                L.rpe_whh_transpose(whh_f, whh_b, whhT)
+                for s in reversed(range(B)):
+                    L.rpe_step_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
+                                   dgh_all[0, s + 1] if s + 1 < B else None, dgh_all[0, s], dgi_sum, whhT, s, B, dsg, dsh)
 
         def rpe_finish():
+            if owner is not None:
+                return
             main.wait_stream(side)
             dxg = self.new(64, 1024)
             for dd, sfx in enumerate(["", "_reverse"]):

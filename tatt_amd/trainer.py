@@ -130,7 +130,9 @@ class SRTrainer:
             L.rotate_fwd(sr, arc, d_sr, B, C, H, W)
             L.rotate_fwd(hr_img, arc, d_hr, B, C, H, W)
             L.rotate_fwd(lr_img, arc, d_lr, B, lr_img.shape[1], lr_img.shape[2], lr_img.shape[3])
-            sr2, ctx2 = self.eng.forward(d_lr, tp, True, 1, wpack=ctx["wpack"])       # seed 1: its own dropout masks
+            # seed 1: its own dropout masks; packed weights and the recurrent positional encoding (a function of the weights alone)
+            # are those of the first pass, whose backward pass below also runs the one BPTT chain for both
+            sr2, ctx2 = self.eng.forward(d_lr, tp, True, 1, wpack=ctx["wpack"], rpe_from=ctx)
             self.tssim = torch.empty(1, device=sr.device)
             L.tri_ssim_fwd(d_sr, sr2, d_hr, self.tssim, B, C, H, W, self.ws_ssim(B * C))
             g_rot, g_sr2 = torch.empty_like(sr), torch.empty_like(sr)
