@@ -216,3 +216,43 @@ def test_eval_matches_oracle_B16():
         sr = m(lr.cuda(), tp.cuda())
         ref = R.tsrn_forward(make_state(37), lr, tp, training=False, fused_rnn=True)
     assert float((sr.cpu() - ref).abs().max()) < 2e-5
+
+
+def test_second_pass_reuses_rpe_chain_of_the_first():
+    """forward(rpe_from=ctx1): the recurrent positional encoding depends on the weights only (model/transformer_v2.py:215-221),
+    so a second pass of the same step (the TSC term) may reuse the first pass's chain and leave the BPTT to it.  Outputs are
+    bit-identical to an independent second pass, the accumulated gradients agree to summation order, and running the backward
+    passes in the wrong order is refused."""
+    B = 3
+    m = build().train()
+    eng = m.engine()
+    g = torch.Generator().manual_seed(11)
+    x1, x2 = torch.rand(B, 4, 16, 64, generator=g).cuda(), torch.rand(B, 4, 16, 64, generator=g).cuda()
+    tp = torch.softmax(torch.randn(B, 37, 1, 26, generator=g), 1).cuda()
+    d1, d2 = torch.randn(B, 4, 32, 128, generator=g).cuda(), torch.randn(B, 4, 32, 128, generator=g).cuda()
+
+    def run(share):
+        buffers = {n: b.clone() for n, b in m.named_buffers()}
+        sr1, c1 = eng.forward(x1, tp, True, 0, p_drop=0.1)
+        sr2, c2 = eng.forward(x2, tp, True, 1, p_drop=0.1, wpack=c1["wpack"], rpe_from=c1 if share else None)
+        G = {n: torch.zeros_like(q) for n, q in m.named_parameters()}
+        eng.backward(c2, d2, G)
+        eng.backward(c1, d1, G)
+        torch.cuda.synchronize()
+        for n, b in m.named_buffers():                 # same running statistics for the second run
+            b.copy_(buffers[n])
+        return sr1.clone(), sr2.clone(), G
+    a1, a2, Ga = run(False)
+    b1, b2, Gb = run(True)
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    for n in Ga:
+        ref, got = Ga[n].double().cpu().numpy(), Gb[n].double().cpu().numpy()
+        assert rel_l2(got, ref) <= 2e-5, (n, rel_l2(got, ref))
+    rpe = [n for n in Ga if "gru_encoding" in n]
+    assert rpe and all(float(Gb[n].abs().sum()) > 0 for n in rpe)
+    # wrong order: the lender's backward before the borrower's
+    sr1, c1 = eng.forward(x1, tp, True, 0)
+    sr2, c2 = eng.forward(x2, tp, True, 1, wpack=c1["wpack"], rpe_from=c1)
+    with pytest.raises(RuntimeError, match="must run its backward first"):
+        eng.backward(c1, d1, {n: torch.zeros_like(q) for n, q in m.named_parameters()})
+    torch.cuda.synchronize()
