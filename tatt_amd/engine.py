@@ -741,9 +741,8 @@ class Engine:
             dca = self.bn_bwd(pre + "bn1.", ca, dma, st1, R0, 64, 2, training, G)
             self.conv_wgrad(blk, dca, G[pre + "conv1.weight"], G[pre + "conv1.bias"], B, H, W, 64, 64, 3)
             self.conv_dgrad(dca, P[pre + "conv1.weight"], ds, B, H, W, 64, 64, 3, acc=1)     # dx = ds + conv1^T(dca)
-            dout = ds
-            self._w_flush()
-        axpby(dout, 1.0, None, 0.0, db1, R0 * 64, 1)
+            dout = ds                                            # (no flush here: the conv weight gradients wait for the next SRB's
+        axpby(dout, 1.0, None, 0.0, db1, R0 * 64, 1)             #  flush, past its latency-bound GRU kernels: 9.48 -> 9.41 ms)
         on_stage("srbs")
 
         # ---- TP interpreter --------------------------------------------------------------------------------------
