@@ -46,7 +46,7 @@ def conv_roofline(L, B, iters=10, bf16=False):
         b = torch.randn(Cout, device="cuda")
         y = torch.empty(B, H, W, Cout, device="cuda")
         sk = Engine._conv_splitk(B * H * W, Cout, 9 * Cin)                   # the engine splits K on the small STN maps
-        calls.append((x, wf, b, y, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 9 * Cin, 1, 0, Cin, 0, 0, sk, ws))
+        calls.append((x, wf, b, y, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 9 * Cin, 1, 0, Cin, 0, 2 if bf16 else 0, sk, ws))
         flops += 2.0 * B * H * W * Cout * 9 * Cin
     for c in calls:
         L.conv_fwd_splitk(*c)
@@ -68,13 +68,14 @@ def conv_roofline(L, B, iters=10, bf16=False):
                 "achieved": round(byts / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byts / dt / 8e12, 4), "traffic": None,
                 "launch_us": round(dt * 1e6, 2), "bytes_per_launch": byts, "tflops": round(ach, 2), "launches_per_step": len(calls)}
     return {"bound": "mfma", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST> (3x3 conv fwd+dgrad, per-step mix of %d launches)" % len(calls),
+            "measured": "standalone replay of the step's launch mix on an otherwise idle GPU, HIP events on the launch stream",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": CONV_TRAFFIC_BYTES, "traffic_note": "bytes per SRB-shaped launch (algorithmic 33.7e6): rocprofv3 --pmc 2*FETCH_SIZE"
             " + WRITE_SIZE, separate passes, profiles/r01_conv_traffic.md (not re-measured by this run)",
             "launch_us": round(dt * 1e6, 2), "flop_per_launch": fl, "launches_per_step": len(calls)}
 
 
-def cpu_baseline(state, B, K, steps=2):
+def cpu_baseline(state, B, K, steps=5):
     """The oracle (CPU restatement of the reference step, stock torch ops) timed on this box's host cores."""
     from oracle import tatt_ref as R
     from tatt_amd.data import synthetic_batch
@@ -84,12 +85,14 @@ def cpu_baseline(state, B, K, steps=2):
     st = {}
     drop = R.HashDropout(0.1, 0)
     R.train_step_config2(P, lr, hr, tp.contiguous(), st, 1, drop=drop, fused_rnn=True)      # warm-up
-    t0 = time.time()
+    ts = []
     for i in range(steps):
+        t0 = time.time()
         R.train_step_config2(P, lr, hr, tp.contiguous(), st, 2 + i, drop=drop, fused_rnn=True)
-    dt = (time.time() - t0) / steps
+        ts.append(time.time() - t0)
+    dt = sorted(ts)[len(ts) // 2]
     return {"value": round(B / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} training steps of the same config-2 workload (B={B}) after 1 warm-up, torch {torch.__version__} CPU"}
+            "sample": f"median of {steps} training steps of the same config-2 workload (B={B}) after 1 warm-up, torch {torch.__version__} CPU"}
 
 
 def main():
@@ -124,37 +127,57 @@ def main():
     from tatt_amd.model.tsrn import TSRN_TL_TRANS
     from tatt_amd.trainer import SRTrainer
 
-    lib().set_matmul_precision(1 if a.bf16 else 0)
     torch.manual_seed(123)
     model = TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32,
                           text_embedding=a.K)
     state_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.cuda().train()
+    model.matmul_precision = "bf16" if a.bf16 else "fp32"
     kw = dict(lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, loss_weight=(1.0, 1e-4), use_graph=not a.no_graph, tsc=a.tsc)
     if a.full:
         from tatt_amd.model.crnn import CRNN
         from tatt_amd.trainer import TATTTrainer
-        trainer = TATTTrainer(model, CRNN().cuda(), CRNN().cuda(), lr_tpg=1e-4, **kw)
+        teacher, student = CRNN().cuda(), CRNN().cuda()
+        teacher.matmul_precision = student.matmul_precision = model.matmul_precision
+        trainer = TATTTrainer(model, teacher, student, lr_tpg=1e-4, **kw)
     else:
         trainer = SRTrainer(model, **kw)
     hr, lr, tp = synthetic_batch(a.batch, a.K, seed=123 + rank, device="cuda")
 
     for _ in range(a.warmup):
         trainer.step(lr, hr, tp)
+    trainer.time_comm = world > 1                    # events around the un-overlapped part of the gradient all-reduce
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         per = trainer.step(lr, hr, tp)
+        marks[i + 1].record()                        # per-step device times (median / p90 below); the metric uses the wall clock
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt_local = dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    dp = {}
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        dts = [float(e.item()) for e in every]
+        dt = max(dts)                                # MAX over ranks
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)                        # the rank count as RCCL itself sees it
+        # self-check: after the timed steps every replica must hold bit-identical parameters and Adam moments
+        # (raises on every rank otherwise -- a diverged run must not report a throughput)
+        checked = trainer.verify_replicas()
+        dp = {"rccl_ranks": dist.get_world_size(), "rccl_ranks_allreduced": int(ones.item()), "replicas_verified_identical": checked,
+              "backend": dist.get_backend(), "rank_ms_per_step_min": round(min(dts) / a.steps * 1e3, 3),
+              "rank_ms_per_step_max": round(max(dts) / a.steps * 1e3, 3),
+              "allreduce_ms_exposed": round(trainer.exposed_comm_ms(), 4), "grad_bytes_per_step": int(trainer.n) * 4,
+              "buckets": [int(b - a_) * 4 for a_, b in trainer.bucket_range]}
     loss = float(per.mean().item()) * 100
     if not (loss == loss and loss < 1e6):
         raise SystemExit(f"non-finite training loss {loss}")
@@ -165,7 +188,9 @@ def main():
         value = a.batch * world * a.steps / dt
         out = {
             "metric": "train images/sec (whole node) TATT 16x64->32x128", "value": round(value, 1), "unit": "images/sec",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "ms_per_step_median": round(per_step[len(per_step) // 2], 3), "ms_per_step_p90": round(per_step[int(0.9 * (len(per_step) - 1))], 3),
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bf16 else "f32", "data": "synthetic",
             "config": {"workload": ("whole reference iteration in %s: CRNN teacher + student priors, SR step%s, SemanticLoss, "
                                     "two-group Adam, K=%d" % (prec, " + TSC" if a.tsc else "", a.K)) if a.full else
@@ -180,6 +205,8 @@ def main():
             "model_tflops": round(value * FLOP_PER_IMAGE_TRAIN * (2 if a.tsc else 1) / 1e12, 2),
             "model_frac_of_f32_mfma_peak": round(value * FLOP_PER_IMAGE_TRAIN * (2 if a.tsc else 1) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
         }
+        if dp:
+            out["data_parallel"] = dp
         out["roofline"] = conv_roofline(lib(), a.batch, bf16=a.bf16)
         if world == 1 and not a.no_cpu_baseline and not a.tsc and not a.full:
             out["cpu_baseline"] = cpu_baseline(state_cpu, a.batch, a.K)

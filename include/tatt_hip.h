@@ -23,6 +23,10 @@
 typedef void* hipStream_t;
 #endif
 
+#define TATT_RELU 1
+#define TATT_ACCUMULATE 1
+#define TATT_BF16 2
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -31,11 +35,19 @@ const char* tatt_last_error(void);
 int tatt_version(void);
 
 /* ---- fp32 MFMA GEMM: every nn.Linear / 1x1 conv / attention projection / GRU input projection ----------
- * C[m*ldc+n] = sum_k A[m*sam+k*sak] * B[n*sbn+k*sbk] (+bias[n]) (+C) (relu).  Replaces F.linear at
+ * C[m*ldc+n] = sum_k A[m*sam+k*sak] * B[n*sbn+k*sbk] (+bias[n]) (+C) (relu).  `flags` (here and in the convolution entry
+ * points) is a bit set, per call -- the library keeps no precision state:
+ *     TATT_RELU (1)        tatt_gemm / tatt_conv_fwd*: ReLU epilogue
+ *     TATT_ACCUMULATE (1)  tatt_conv_wgrad / tatt_conv_skinny_fwd: add to the destination
+ *     TATT_BF16 (2)        operands rounded to bf16 (nearest-even) on their way into v_mfma_f32_32x32x16_bf16, fp32 accumulation
+ *                          (BASELINE.json config 3; the reference itself has no autocast).  Default = exact fp32 operands on
+ *                          v_mfma_f32_32x32x2_f32, the parity path.  Launches whose shapes take the generic (non-FAST) loaders
+ *                          stay fp32 either way; tensors in memory are fp32 in both modes.
+ * Replaces F.linear at
  * model/tsrn.py:213, :1083 (1x1 conv), model/transformer_v2.py:476,:480,:819,:829 (MHA in/out proj, FFN),
  * nn.GRU input projections (model/tsrn.py:1088, model/transformer_v2.py:218), stn_head.py:99-100. */
 size_t tatt_gemm_workspace(int M, int N, int splitk);
-int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int batch, long sAb, long sBb, long sCb, int accumulate, int relu, int splitk, float* workspace, hipStream_t stream);
+int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int batch, long sAb, long sBb, long sCb, int accumulate, int flags, int splitk, float* workspace, hipStream_t stream);
 
 /* Weight + bias gradient of a Linear / 1x1 conv with a small output (M <= 96, N <= 64): dW[M,N] += dY[R,M]^T X[R,N],
  * db[M] += colsum(dY) in ONE streaming pass over the R rows (autograd of F.linear at the sites above). */
@@ -50,10 +62,10 @@ int tatt_tn_small_group(int nprob, const float* const* dY, const long* lddy, con
  * Replaces nn.Conv2d at model/tsrn.py:598 (9x9 4->64), :868,:876 (SRB 3x3), :614, :1034 (64->256), :625
  * (9x9 64->4) and model/stn_head.py:15.  Weights stay in the reference's OIHW layout; (w_sn,w_sci,w_base,
  * w_stap) describe how (cout, cin, tap) is addressed: forward (Cin*T, T, 0, 1); dgrad (T, Cin_f*T, T-1, -1). */
-int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu, hipStream_t stream);
+int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int flags, hipStream_t stream);
 /* tatt_conv_fwd with the KH*KW*Cin reduction split `splitk` ways (workspace: splitk*B*H*W*Cout floats): the small feature
  * maps of the STN head (model/stn_head.py:15, 4x8 .. 2x2 pixels, K up to 2304) have too few output tiles to fill the chip. */
-int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu, int splitk, float* workspace, hipStream_t stream);
+int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int flags, int splitk, float* workspace, hipStream_t stream);
 /* Per-step weight repack for tatt_conv_fwd (same nn.Conv2d weights as above): Wf[co][tap][ci] for the forward pass,
  * strides (T*Cin, 1, 0, Cin), and Wd[ci][tap][co] with the taps already flipped for dgrad, strides (T*Cout, 1, 0, Cout):
  * the kernel's weight-tile loads become 16-byte contiguous instead of stride-T gathers. */
@@ -63,9 +75,9 @@ int tatt_conv_pack_w_group(int n, const float* const* Wt, float* const* Wf, floa
 /* Cout in {4,8,16} (9x9 64->4 output conv model/tsrn.py:625 and the dgrad of the 9x9 4->64 conv :598): dense planar GEMM
  * Z[(tap,co)][pixel] followed by a shifted gather-sum, instead of padding Cout to the 64-wide MFMA tile. */
 size_t tatt_conv_skinny_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW);
-int tatt_conv_skinny_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, float* workspace, hipStream_t stream);
+int tatt_conv_skinny_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int flags, float* workspace, hipStream_t stream);
 size_t tatt_conv_wgrad_workspace(int Cin, int Cout, int KH, int KW, int splitk);
-int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long lddy, int splitk, float* workspace, int accumulate, hipStream_t stream);
+int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long lddy, int splitk, float* workspace, int flags, hipStream_t stream);
 
 /* ---- BatchNorm2d/1d (model/tsrn.py:869,:877,:615; model/stn_head.py:19,:51) ------------------------------- */
 size_t tatt_bn_workspace(int C);
@@ -177,14 +189,6 @@ int tatt_ctc_greedy(const float* logits, int* arg, int* codes, int* lens, int T,
 /* F.interpolate(x, (OH, OW), mode="bicubic") on `planes` = B*C contiguous [H][W] planes: the LR image at SR size for the
  * psnr_lr / ssim_lr metrics of the eval loop (interfaces/super_resolution_eng.py:486). */
 int tatt_bicubic_resize(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t stream);
-
-/* ---- matrix-core precision (no counterpart in the reference, which has no autocast; BASELINE.json config 3 asks for a bf16
- * step).  Process-wide switch read by tatt_gemm / tatt_conv_fwd* / tatt_conv_wgrad at launch time: 0 = fp32 operands on
- * v_mfma_f32_32x32x2_f32 (default, the parity path), 1 = operands rounded to bf16 (nearest-even) on their way into
- * v_mfma_f32_32x32x16_bf16, fp32 accumulation; tensors in memory, the recurrent kernels, normalisations, losses and the
- * optimiser stay fp32.  Launches whose shapes take the generic (non-FAST) loaders stay fp32 in both modes. */
-int tatt_set_matmul_precision(int mode);
-int tatt_get_matmul_precision(void);
 
 /* ---- input transform: resizeNormalize.__call__ (dataset/dataset.py:282-325) per sample of
  * alignCollate.__call__ (:677-693) = PIL resize(BICUBIC) -> ToTensor -> mask channel (1 where L <= mean L), bit-exact with

@@ -9,6 +9,11 @@
 #define TATT_ERR_ARG 1
 #define TATT_ERR_LAUNCH 2
 
+// bits of the `flags` argument of the GEMM / convolution entry points (include/tatt_hip.h)
+#define TATT_RELU 1        // tatt_gemm, tatt_conv_fwd*: ReLU epilogue
+#define TATT_ACCUMULATE 1  // tatt_conv_wgrad, tatt_conv_skinny_fwd: add to the destination
+#define TATT_BF16 2        // operands rounded to bf16 (nearest-even) into v_mfma_f32_32x32x16_bf16, fp32 accumulate
+
 void tatt_set_error(const char* fmt, ...);
 
 #define TATT_CHECK_ARG(cond, ...)                 \

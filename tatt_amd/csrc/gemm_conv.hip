@@ -43,6 +43,7 @@ struct GemmArgs {
   int kchunk;     // K range per split (multiple of BK)
   int accumulate; // C += result
   int relu;
+  int bf16;       // host only: operands rounded to bf16 on their way into the matrix core (TATT_BF16 flag of the entry point)
   ConvGeom g;     // for OP_IM2COL / OP_CONVW / OP_IM2COL_N
   long w_sn, w_sci, w_stap, w_base;  // OP_CONVW: W[n*w_sn + ci*w_sci + w_base + tap*w_stap]
 };
@@ -725,7 +726,6 @@ bool fast_ok(const GemmArgs& a) {
   return ok;
 }
 
-int g_matmul_bf16 = 0;  // tatt_set_matmul_precision
 const int g_tap9 = [] { const char* e = getenv("TATT_CONV_TAP9"); return (e && e[0] == '0') ? 0 : 1; }();  // =0: generic loop (A/B runs)
 
 template <int AOP, int BOP>
@@ -733,14 +733,14 @@ int launch(const GemmArgs& a, int batch, hipStream_t st) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch * a.splitk);
   if constexpr (AOP == OP_IM2COL && BOP == OP_CONVW_P) {  // 3x3, Cin = 64, packed weights, whole K in one pass: tap-unrolled loop
     if (g_tap9 && fast_ok<AOP, BOP>(a) && a.g.Cin == 64 && a.g.KH == 3 && a.g.KW == 3 && a.splitk == 1 && a.K == 576 && a.w_stap == 64) {
-      if (g_matmul_bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, true>), grid, dim3(NTHR), 0, st, a);
+      if (a.bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, true>), grid, dim3(NTHR), 0, st, a);
       else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, false, true>), grid, dim3(NTHR), 0, st, a);
       TATT_LAUNCH_CHECK("gemm_kernel<tap9>");
       return TATT_OK;
     }
   }
   if (fast_ok<AOP, BOP>(a)) {
-    if (g_matmul_bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true>), grid, dim3(NTHR), 0, st, a);
+    if (a.bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true>), grid, dim3(NTHR), 0, st, a);
     else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true>), grid, dim3(NTHR), 0, st, a);
   } else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, false>), grid, dim3(NTHR), 0, st, a);
   TATT_LAUNCH_CHECK("gemm_kernel");
@@ -750,13 +750,6 @@ int launch(const GemmArgs& a, int batch, hipStream_t st) {
 }  // namespace
 
 extern "C" {
-
-int tatt_set_matmul_precision(int mode) {
-  TATT_CHECK_ARG(mode == 0 || mode == 1, "tatt_set_matmul_precision: mode is 0 (fp32) or 1 (bf16 operands, fp32 accumulate)");
-  g_matmul_bf16 = mode;
-  return TATT_OK;
-}
-int tatt_get_matmul_precision(void) { return g_matmul_bf16; }
 
 int tatt_conv_pack_w(const float* Wt, float* Wf, float* Wd, int Cout, int Cin, int KH, int KW, hipStream_t st) {
   TATT_CHECK_ARG(Wt && Wf && Wd && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "tatt_conv_pack_w: bad arguments");
@@ -790,8 +783,9 @@ int tatt_conv_pack_w_group(int n, const float* const* Wt, float* const* Wf, floa
 size_t tatt_gemm_workspace(int M, int N, int splitk) { return splitk > 1 ? (size_t)M * N * splitk : 0; }
 
 int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sam, long sak,
-              long sbn, long sbk, long ldc, int batch, long sAb, long sBb, long sCb, int accumulate, int relu, int splitk,
+              long sbn, long sbk, long ldc, int batch, long sAb, long sBb, long sCb, int accumulate, int flags, int splitk,
               float* workspace, hipStream_t st) {
+  const int relu = flags & TATT_RELU;
   TATT_CHECK_ARG(M > 0 && N > 0 && K >= 0 && batch > 0, "tatt_gemm: bad dims M=%d N=%d K=%d batch=%d", M, N, K, batch);
   TATT_CHECK_ARG(splitk >= 1 && (splitk == 1 || workspace), "tatt_gemm: split-K needs a workspace");
   TATT_CHECK_ARG(splitk == 1 || batch == 1 || bias == nullptr, "tatt_gemm: batched split-K takes no bias");
@@ -802,7 +796,7 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
   a.sam = sam; a.sak = sak; a.sbn = sbn; a.sbk = sbk; a.ldc = ldc;
   a.sAb = sAb; a.sBb = sBb; a.sCb = sCb;
   a.splitk = splitk;
-  a.accumulate = accumulate; a.relu = relu;
+  a.accumulate = accumulate; a.relu = relu; a.bf16 = (flags & TATT_BF16) != 0;
   a.kchunk = cdiv(cdiv(K, splitk), BK) * BK;
   if (a.kchunk == 0) a.kchunk = BK;
   if (splitk > 1) {  // slabs [batch][splitk][M][N]
@@ -832,13 +826,13 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
 //   forward with OIHW weights [Cout,Cin,KH,KW]:  w_sn=Cin*T, w_sci=T, w_base=0,   w_stap=1
 //   dgrad (X:=dY, Cin:=Cout_f, Cout:=Cin_f):     w_sn=T,     w_sci=Cin_f*T, w_base=T-1, w_stap=-1
 int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH,
-                         int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu,
+                         int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int flags,
                          int splitk, float* workspace, hipStream_t st);
 
 int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH,
-                  int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu,
+                  int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int flags,
                   hipStream_t st) {
-  return tatt_conv_fwd_splitk(X, Wt, bias, Y, B, H, W, Cin, Cout, KH, KW, ldx, ldy, w_sn, w_sci, w_base, w_stap, accumulate, relu, 1,
+  return tatt_conv_fwd_splitk(X, Wt, bias, Y, B, H, W, Cin, Cout, KH, KW, ldx, ldy, w_sn, w_sci, w_base, w_stap, accumulate, flags, 1,
                               nullptr, st);
 }
 
@@ -846,8 +840,9 @@ int tatt_conv_fwd(const float* X, const float* Wt, const float* bias, float* Y, 
 // second kernel sums (+bias, +Y, relu): for the small feature maps of the STN head (a handful of output tiles, K up to
 // 2304) one workgroup per tile would walk 72 K-tiles in sequence while 250 CUs idle.
 int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH,
-                         int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int relu,
+                         int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate, int flags,
                          int splitk, float* workspace, hipStream_t st) {
+  const int relu = flags & TATT_RELU;
   TATT_CHECK_ARG(splitk >= 1 && (splitk == 1 || workspace), "tatt_conv_fwd_splitk: split-K needs a workspace");
   TATT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "tatt_conv_fwd: bad dims");
   TATT_CHECK_ARG(Cin % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)X) & 15) == 0, "tatt_conv_fwd: Cin/ldx must be multiples of 4, X 16B aligned");
@@ -860,7 +855,7 @@ int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, flo
   a.ldc = ldy;
   a.splitk = splitk;
   a.kchunk = cdiv(cdiv(a.K, splitk), BK) * BK;
-  a.accumulate = accumulate; a.relu = relu;
+  a.accumulate = accumulate; a.relu = relu; a.bf16 = (flags & TATT_BF16) != 0;
   a.g = ConvGeom{H, W, Cin, KH, KW, KH / 2, KW / 2, (int)ldx};
   a.w_sn = w_sn; a.w_sci = w_sci; a.w_base = w_base; a.w_stap = w_stap;
   if (splitk > 1) {
@@ -886,8 +881,9 @@ size_t tatt_conv_skinny_workspace(int B, int H, int W, int Cin, int Cout, int KH
 
 // Same contract as tatt_conv_fwd (no relu) for Cout in {4, 8, 16}; see the kernels above.
 int tatt_conv_skinny_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH,
-                         int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int accumulate,
+                         int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int flags,
                          float* workspace, hipStream_t st) {
+  const int accumulate = flags & TATT_ACCUMULATE;
   TATT_CHECK_ARG(Cout == 4 || Cout == 8 || Cout == 16, "tatt_conv_skinny_fwd: Cout must be 4, 8 or 16 (got %d)", Cout);
   TATT_CHECK_ARG(workspace && (KH & 1) && (KW & 1) && B > 0, "tatt_conv_skinny_fwd: bad arguments");
   const int T = KH * KW;
@@ -904,6 +900,7 @@ int tatt_conv_skinny_fwd(const float* X, const float* Wt, const float* bias, flo
   a.M = T * Cout; a.N = (int)P; a.K = Cin;
   a.sam = Cin; a.sak = 1; a.sbn = ldx; a.sbk = 1; a.ldc = P;
   a.splitk = 1;
+  a.bf16 = (flags & TATT_BF16) != 0;
   a.kchunk = cdiv(Cin, BK) * BK;
   int rc = launch<OP_STRIDED, OP_STRIDED>(a, 1, st);
   if (rc) return rc;
@@ -921,7 +918,8 @@ size_t tatt_conv_wgrad_workspace(int Cin, int Cout, int KH, int KW, int splitk) 
 
 // dW[co,ci,kh,kw] (+)= sum_p dY[p,co] * X[p+tap, ci]   (OIHW output), split over pixels.
 int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, int W, int Cin, int Cout, int KH, int KW,
-                    long ldx, long lddy, int splitk, float* workspace, int accumulate, hipStream_t st) {
+                    long ldx, long lddy, int splitk, float* workspace, int flags, hipStream_t st) {
+  const int accumulate = flags & TATT_ACCUMULATE;
   TATT_CHECK_ARG(Cin % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)X) & 15) == 0, "tatt_conv_wgrad: Cin/ldx multiples of 4");
   TATT_CHECK_ARG(splitk >= 1 && workspace, "tatt_conv_wgrad: workspace required");
   TATT_CHECK_ARG((long)B * H * W * ldx * 4 < (1L << 31) && (long)B * H * W * lddy * 4 < (1L << 31), "tatt_conv_wgrad: operands must stay below 2 GiB (32-bit buffer offsets)");
@@ -935,6 +933,7 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
   a.splitk = splitk;
   a.sCz = (long)a.M * a.N;
   a.kchunk = cdiv(cdiv(a.K, splitk), BK) * BK;
+  a.bf16 = (flags & TATT_BF16) != 0;
   a.g = ConvGeom{H, W, Cin, KH, KW, KH / 2, KW / 2, (int)ldx};
   int perm = 1, perm_c = Cin;
   if (Cout <= 16 && Cout % 4 == 0 && lddy % 4 == 0 && (((uintptr_t)dY) & 15) == 0) {

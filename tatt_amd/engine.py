@@ -62,6 +62,12 @@ class Engine:
         # their ramp-up and under-filled tails overlap with the dgrad chain; see _wgrad().  "off" = in line on the main stream.
         # Measured at B=64 (ms/step): off 12.82, one fork per kernel 12.92 (each cross-stream dependency costs more than it
         # hides), one fork per half SRB 12.23.  Upper bound if the 3.8 ms of weight-gradient kernels were free: 8.99.
+        # Matrix-core precision of THIS engine's launches (a per-call flag of the C-ABI, no process state): 0 = exact fp32 operands,
+        # TATT_BF16 = operands rounded to bf16 into the MFMA, fp32 accumulate.  Set per forward call from module.matmul_precision
+        # and kept in the call's context for its backward pass.  The STN head, the TPS matrices and the recurrent positional
+        # encoding stay fp32 in both modes (self.pf is not applied there): control points are scaled x64 into pixel coordinates
+        # by grid_sample and the RPE feeds every query, so their rounding error is amplified instead of averaged out.
+        self.pf = 0
         self.wgrad_mode = os.environ.get("TATT_WGRAD_STREAM", "batch")
         if self.wgrad_mode not in ("batch", "off"):
             raise RuntimeError("TATT_WGRAD_STREAM must be 'batch' or 'off'")
@@ -119,7 +125,11 @@ class Engine:
             return
         main = torch.cuda.current_stream()
         if self._wside is None or self._wside[0].device != self.dev:
+            # 1 or 2: with the main chain and the RPE chain that is at most four concurrent branches, the number of internal
+            # queues the HIP runtime runs a graph on (forcing more queues crashed hipStreamEndCapture on this ROCm)
             n = int(os.environ.get("TATT_WGRAD_STREAMS", "2"))
+            if n not in (1, 2):
+                raise RuntimeError(f"TATT_WGRAD_STREAMS must be 1 or 2 (got {n})")
             self._wside = [torch.cuda.Stream(device=self.dev) for _ in range(n)]
             self.ws_w = [torch.empty(WS_FLOATS, device=self.dev, dtype=torch.float32) for _ in range(n)]
             self._w_rr = 0
@@ -148,6 +158,13 @@ class Engine:
         if self._w_pending and t is not None and t.untyped_storage().data_ptr() in self._w_pending:
             self._w_join()
 
+    def reset_streams(self):
+        """Drop every forked stream and queued weight-gradient launch (after a failed hipGraph capture the old streams may be
+        left in an invalidated capture state; fresh ones are created on demand)."""
+        self._side = self._enc = self._wside = self.ws_w = None
+        self._w_used = set()
+        self._w_keep, self._w_pending, self._w_defer = [], set(), []
+
     def enc_stream(self):
         if self._enc is None or self._enc.device != self.dev:
             self._enc = torch.cuda.Stream(device=self.dev)
@@ -167,21 +184,22 @@ class Engine:
             s //= 2
         return max(1, s)
 
-    def linear(self, x, W, b, out, R, N, K, ldx=None, ldw=None, ldc=None, acc=0, relu=0, splitk=1):
+    def linear(self, x, W, b, out, R, N, K, ldx=None, ldw=None, ldc=None, acc=0, relu=0, splitk=1, fp32=False):
         """out[R,N] (+)= x[R,K] @ W[N,K]^T + b   (splitk > 1 for the few-row, long-K products of the RPE)"""
-        self.L.gemm(x, W, out, b, R, N, K, ldx or K, 1, ldw or K, 1, ldc or N, 1, 0, 0, 0, acc, relu, splitk,
-                    self.ws if splitk > 1 else None)
+        self.L.gemm(x, W, out, b, R, N, K, ldx or K, 1, ldw or K, 1, ldc or N, 1, 0, 0, 0, acc, relu | (0 if fp32 else self.pf),
+                    splitk, self.ws if splitk > 1 else None)
 
-    def linear_dx(self, dy, W, dx, R, N, K, lddy=None, ldw=None, lddx=None, acc=0, splitk=1):
+    def linear_dx(self, dy, W, dx, R, N, K, lddy=None, ldw=None, lddx=None, acc=0, splitk=1, fp32=False):
         """dx[R,K] (+)= dy[R,N] @ W[N,K]"""
         self._guard(dx)
-        self.L.gemm(dy, W, dx, None, R, K, N, lddy or N, 1, 1, ldw or K, lddx or K, 1, 0, 0, 0, acc, 0, splitk,
+        self.L.gemm(dy, W, dx, None, R, K, N, lddy or N, 1, 1, ldw or K, lddx or K, 1, 0, 0, 0, acc, 0 if fp32 else self.pf, splitk,
                     self.ws if splitk > 1 else None)
 
-    def linear_dw(self, dy, x, dW, R, N, K, lddy=None, ldx=None, lddw=None):
+    def linear_dw(self, dy, x, dW, R, N, K, lddy=None, ldx=None, lddw=None, fp32=False):
         """dW[N,K] += dy[R,N]^T @ x[R,K]  (always accumulates into the gradient buffer)"""
         sk = self._splitk(N, K, R)
-        self._wgrad(lambda ws: self.L.gemm(dy, x, dW, None, N, K, R, 1, lddy or N, 1, ldx or K, lddw or K, 1, 0, 0, 0, 1, 0, sk,
+        fl = 0 if fp32 else self.pf
+        self._wgrad(lambda ws: self.L.gemm(dy, x, dW, None, N, K, R, 1, lddy or N, 1, ldx or K, lddw or K, 1, 0, 0, 0, 1, fl, sk,
                                            ws if sk > 1 else None), [dy], [x])
 
     def linear_dwb(self, dy, x, dW, db, R, N, K, lddy=None, ldx=None, lddw=None):
@@ -211,10 +229,10 @@ class Engine:
     def colsum(self, x, R, C, out, ld=None):
         self._wgrad(lambda ws: self.L.colsum(x, ld or C, R, C, out, 1, ws), [x])
 
-    def _skinny(self, x, W, b, out, B, H, Wd, Cin, Cout, k, wstr, acc):
+    def _skinny(self, x, W, b, out, B, H, Wd, Cin, Cout, k, wstr, acc, fp32=False):
         wsz = self.L.conv_skinny_workspace(B, H, Wd, Cin, Cout, k, k)
         z = self.new(wsz)                                      # planar Z [(tap,co)][pixel]: 340 MB for the output conv at B=64
-        self.L.conv_skinny_fwd(x, W, b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout, *wstr, acc, z)
+        self.L.conv_skinny_fwd(x, W, b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout, *wstr, acc | (0 if fp32 else self.pf), z)
 
     def _prepack(self, use_stn):
         """Pack every convolution weight of the network for this forward call with ONE launch (tatt_conv_pack_w_group)."""
@@ -265,23 +283,24 @@ class Engine:
             sk //= 2
         return max(1, sk)
 
-    def conv(self, x, W, b, out, B, H, Wd, Cin, Cout, k, acc=0, relu=0):
+    def conv(self, x, W, b, out, B, H, Wd, Cin, Cout, k, acc=0, relu=0, fp32=False):
         T = k * k
         if Cout in (4, 8, 16) and not relu:
             return self._skinny(x, W, b, out, B, H, Wd, Cin, Cout, k, (Cin * T, T, 0, 1), acc)
         self.L.conv_fwd_splitk(x, self._packed(W, Cout, Cin, k)[0], b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout,
-                               T * Cin, 1, 0, Cin, acc, relu, self._conv_splitk(B * H * Wd, Cout, T * Cin), self.ws)
+                               T * Cin, 1, 0, Cin, acc, relu | (0 if fp32 else self.pf), self._conv_splitk(B * H * Wd, Cout, T * Cin),
+                               self.ws)
 
-    def conv_dgrad(self, dy, W, dx, B, H, Wd, Cin, Cout, k, acc=0):
+    def conv_dgrad(self, dy, W, dx, B, H, Wd, Cin, Cout, k, acc=0, fp32=False):
         """dx[B,H,W,Cin] (+)= conv^T(dy[B,H,W,Cout]);  W is the forward OIHW weight [Cout,Cin,k,k]."""
         T = k * k
         self._guard(dx)
         if Cin in (4, 8, 16):
-            return self._skinny(dy, W, None, dx, B, H, Wd, Cout, Cin, k, (T, Cin * T, T - 1, -1), acc)
+            return self._skinny(dy, W, None, dx, B, H, Wd, Cout, Cin, k, (T, Cin * T, T - 1, -1), acc, fp32)
         self.L.conv_fwd_splitk(dy, self._packed(W, Cout, Cin, k)[1], None, dx, B, H, Wd, Cout, Cin, k, k, Cout, Cin,
-                               T * Cout, 1, 0, Cout, acc, 0, self._conv_splitk(B * H * Wd, Cin, T * Cout), self.ws)
+                               T * Cout, 1, 0, Cout, acc, 0 if fp32 else self.pf, self._conv_splitk(B * H * Wd, Cin, T * Cout), self.ws)
 
-    def conv_wgrad(self, x, dy, dW, db, B, H, Wd, Cin, Cout, k):
+    def conv_wgrad(self, x, dy, dW, db, B, H, Wd, Cin, Cout, k, fp32=False):
         T = k * k
         if Cout <= 16:                                         # roles swapped: M = Cin, N = T*Cout (see tatt_conv_wgrad)
             tiles = -(-Cin // 128) * -(-(T * Cout) // 64)
@@ -292,7 +311,8 @@ class Engine:
         sk = max(1, min((B * H * Wd) // 256, -(-768 // tiles)))        # ~3 workgroups per CU (swept 256..1536: flat within 1 %)
         while sk > 1 and Cout * T * Cin * sk > WS_FLOATS:
             sk //= 2
-        self._wgrad(lambda ws: self.L.conv_wgrad(x, dy, dW, B, H, Wd, Cin, Cout, k, k, Cin, Cout, sk, ws, 1), [dy], [x])
+        fl = 1 | (0 if fp32 else self.pf)
+        self._wgrad(lambda ws: self.L.conv_wgrad(x, dy, dW, B, H, Wd, Cin, Cout, k, k, Cin, Cout, sk, ws, fl), [dy], [x])
         self.colsum(dy, B * H * Wd, Cout, db)
 
     def bn(self, pre, x, R, C, train, act, out=None, res=None):
@@ -487,6 +507,10 @@ class Engine:
         p = (m.dropout_p if p_drop is None else p_drop) if training else 0.0
         cfg = lambda site: self.dropcfg(site, seed, p)
         ctx = Ctx()
+        prec = getattr(m, "matmul_precision", "fp32")
+        if prec not in ("fp32", "bf16"):
+            raise RuntimeError(f"matmul_precision must be 'fp32' or 'bf16', got {prec!r}")
+        self.pf = ctx["pf"] = 2 if prec == "bf16" else 0
         ctx["meta"] = (B, training, seed, p)
         self.wpack = ctx["wpack"] = {} if wpack is None else wpack   # weights change every step: repacked per forward call
         R0 = B * H * W
@@ -515,8 +539,8 @@ class Engine:
             xg = self.new(64, 1024)
             L.rpe_gather_x(P[ig + "init_factor.weight"], xg)
             gi = self.new(2, 64, 1536)
-            self.linear(xg, P[g + "weight_ih_l0"], P[g + "bias_ih_l0"], gi[0], 64, 1536, 1024, splitk=8)
-            self.linear(xg, P[g + "weight_ih_l0_reverse"], P[g + "bias_ih_l0_reverse"], gi[1], 64, 1536, 1024, splitk=8)
+            self.linear(xg, P[g + "weight_ih_l0"], P[g + "bias_ih_l0"], gi[0], 64, 1536, 1024, splitk=8, fp32=True)
+            self.linear(xg, P[g + "weight_ih_l0_reverse"], P[g + "bias_ih_l0_reverse"], gi[1], 64, 1536, 1024, splitk=8, fp32=True)
             hstep = self.zeros(2, B + 1, 64, 512)
             gh_all = self.new(2, B, 64, 1536)
             qp = self.new(R0, 64)
@@ -566,7 +590,7 @@ class Engine:
                 pre = f"stn_head.stn_convnet.{idx}."
                 Rr = B * hh * ww
                 c = self.new(Rr, cout)
-                self.conv(h, P[pre + "0.weight"], P[pre + "0.bias"], c, B, hh, ww, cin, cout, 3)
+                self.conv(h, P[pre + "0.weight"], P[pre + "0.bias"], c, B, hh, ww, cin, cout, 3, fp32=True)
                 a, stat = self.bn(pre + "1.", c, Rr, cout, True, 1)
                 rec = [h, c, stat, a, hh, ww]
                 if pool is not None:
@@ -579,12 +603,12 @@ class Engine:
             f = self.new(B, 512)
             L.nhwc_to_nchw(h, f, B, 256, 2)                                   # flatten order of x.view(B,-1) on NCHW
             l1 = self.new(B, 512)
-            self.linear(f, P["stn_head.stn_fc1.0.weight"], P["stn_head.stn_fc1.0.bias"], l1, B, 512, 512)
+            self.linear(f, P["stn_head.stn_fc1.0.weight"], P["stn_head.stn_fc1.0.bias"], l1, B, 512, 512, fp32=True)
             feat, stat1 = self.bn("stn_head.stn_fc1.1.", l1, B, 512, True, 1)
             feat01 = self.new(B, 512)
             L.axpby(feat, 0.1, None, 0.0, feat01, B * 512, 0)
             ctrl = self.new(B, 40)
-            self.linear(feat01, P["stn_head.stn_fc2.weight"], P["stn_head.stn_fc2.bias"], ctrl, B, 40, 512)
+            self.linear(feat01, P["stn_head.stn_fc2.weight"], P["stn_head.stn_fc2.bias"], ctrl, B, 40, 512, fp32=True)
             Tm = self.new(H * W, 20)                                          # target_coordinate_repr @ inverse_kernel[:, :20]
             L.gemm(P["tps.target_coordinate_repr"], P["tps.inverse_kernel"], Tm, None, H * W, 20, 23, 23, 1, 1, 23, 20,
                    1, 0, 0, 0, 0, 0, 1, None)
@@ -695,6 +719,7 @@ class Engine:
             L.axpby(x, a, y, b, out, n, accumulate)
         L, m, P = self.L, self.m, self.P
         B, training, seed, p = ctx["meta"]
+        self.pf = ctx["pf"]
         self.wpack = ctx["wpack"]
         cfg = lambda site: self.dropcfg(site, seed, p)
         H, W = 16, 64
@@ -805,11 +830,11 @@ class Engine:
             main.wait_stream(side)
             dxg = self.new(64, 1024)
             for dd, sfx in enumerate(["", "_reverse"]):
-                self.linear_dw(dgh_all[dd], hstep[dd], G[g + "weight_hh_l0" + sfx], 64 * B, 1536, 512)
+                self.linear_dw(dgh_all[dd], hstep[dd], G[g + "weight_hh_l0" + sfx], 64 * B, 1536, 512, fp32=True)
                 self.colsum(dgh_all[dd], 64 * B, 1536, G[g + "bias_hh_l0" + sfx])
-                self.linear_dw(dgi_sum[dd], xg, G[g + "weight_ih_l0" + sfx], 64, 1536, 1024)
+                self.linear_dw(dgi_sum[dd], xg, G[g + "weight_ih_l0" + sfx], 64, 1536, 1024, fp32=True)
                 self.colsum(dgi_sum[dd], 64, 1536, G[g + "bias_ih_l0" + sfx])
-                self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd, splitk=8)
+                self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd, splitk=8, fp32=True)
             L.rpe_scatter_dx(dxg, G[ig + "init_factor.weight"], 1)
         # encoder
         e = tr + "encoder.layers.0."
@@ -841,23 +866,23 @@ class Engine:
         # ---- TPS + STN head ----------------------------------------------------------------------------------------
         stn_saved, f, l1, stat1, feat01, ctrl, Tm = ctx["stn"]
         dxs = self.new(R0, 4)
-        self.conv_dgrad(dc1, P["block1.0.weight"], dxs, B, H, W, 4, 64, 9)
+        self.conv_dgrad(dc1, P["block1.0.weight"], dxs, B, H, W, 4, 64, 9, fp32=True)
         dctrl = self.new(B, 40)
         L.tps_sample_bwd(ctx["x"], ctrl, Tm, dxs, dctrl, B, 4, H, W, 0)
         # The RPE chain (forked after the decoder) has ended by now at the benchmark shapes: its input-gradient GEMMs go here and
         # its weight gradients join the queue, so that they overlap with the STN head's backward pass instead of trailing it.
         rpe_finish()
         self._w_flush()
-        self.linear_dw(dctrl, feat01, G["stn_head.stn_fc2.weight"], B, 40, 512)
+        self.linear_dw(dctrl, feat01, G["stn_head.stn_fc2.weight"], B, 40, 512, fp32=True)
         self.colsum(dctrl, B, 40, G["stn_head.stn_fc2.bias"])
         dfeat = self.new(B, 512)
-        self.linear_dx(dctrl, P["stn_head.stn_fc2.weight"], dfeat, B, 40, 512)
+        self.linear_dx(dctrl, P["stn_head.stn_fc2.weight"], dfeat, B, 40, 512, fp32=True)
         axpby(dfeat, 0.1, None, 0.0, dfeat, B * 512, 0)
         dl1 = self.bn_bwd("stn_head.stn_fc1.1.", l1, dfeat, stat1, B, 512, 1, True, G)
-        self.linear_dw(dl1, f, G["stn_head.stn_fc1.0.weight"], B, 512, 512)
+        self.linear_dw(dl1, f, G["stn_head.stn_fc1.0.weight"], B, 512, 512, fp32=True)
         self.colsum(dl1, B, 512, G["stn_head.stn_fc1.0.bias"])
         df = self.new(B, 512)
-        self.linear_dx(dl1, P["stn_head.stn_fc1.0.weight"], df, B, 512, 512)
+        self.linear_dx(dl1, P["stn_head.stn_fc1.0.weight"], df, B, 512, 512, fp32=True)
         dh = self.new(B * 2, 256)
         L.nchw_to_nhwc(df, dh, B, 256, 2)
         for (idx, cin, cout, pool), rec in zip(reversed(STN_STAGES), reversed(stn_saved)):
@@ -872,10 +897,10 @@ class Engine:
             dc = self.bn_bwd(pre + "1.", c, da, stat, Rr, cout, 1, True, G)
             if self.debug is not None:
                 self.debug[f"stn{idx}"] = (dh.clone(), da.clone(), dc.clone())
-            self.conv_wgrad(hin, dc, G[pre + "0.weight"], G[pre + "0.bias"], B, hh, ww, cin, cout, 3)
+            self.conv_wgrad(hin, dc, G[pre + "0.weight"], G[pre + "0.bias"], B, hh, ww, cin, cout, 3, fp32=True)
             if idx > 0:
                 dh = self.new(Rr, cin)
-                self.conv_dgrad(dc, P[pre + "0.weight"], dh, B, hh, ww, cin, cout, 3)
+                self.conv_dgrad(dc, P[pre + "0.weight"], dh, B, hh, ww, cin, cout, 3, fp32=True)
             if idx in (8, 4):
                 self._w_flush()
         on_stage("head")

@@ -58,7 +58,7 @@ class _Lib:
             setattr(self, name[len("tatt_"):], self._wrap(name, fn, res, takes_stream, len(args)))
 
     def _wrap(self, name, fn, res, takes_stream, nargs):
-        is_status = res is ctypes.c_int and name not in ("tatt_version", "tatt_get_matmul_precision")
+        is_status = res is ctypes.c_int and name not in ("tatt_version",)
 
         def call(*args):
             conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]

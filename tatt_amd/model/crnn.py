@@ -60,6 +60,10 @@ class _Plan:
                     raise RuntimeError(f"buffer {k} must be contiguous fp32 (it is updated in place)")
                 v = v.float().contiguous()
             out[k] = v
+        prec = getattr(self.m, "matmul_precision", "fp32")
+        if prec not in ("fp32", "bf16"):
+            raise RuntimeError(f"matmul_precision must be 'fp32' or 'bf16', got {prec!r}")
+        self.pf = 2 if prec == "bf16" else 0          # TATT_BF16 flag of the GEMM / convolution entry points (per call)
         self.dev = next(iter(out.values())).device
         if self.ws is None or self.ws.device != self.dev:
             self.ws = torch.empty(WS_FLOATS, device=self.dev)
@@ -72,7 +76,7 @@ class _Plan:
         wf, wd = self.new(Cout * 9 * Cin), self.new(Cout * 9 * Cin)
         L.conv_pack_w(P[f"cnn.conv{i}.weight"], wf, wd, Cout, Cin, 3, 3)
         packs[i] = wd
-        L.conv_fwd(x, wf, P[f"cnn.conv{i}.bias"], y, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 9 * Cin, 1, 0, Cin, 0, relu)
+        L.conv_fwd(x, wf, P[f"cnn.conv{i}.bias"], y, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 9 * Cin, 1, 0, Cin, 0, relu | self.pf)
         return y
 
     def bn_relu(self, P, i, x, R, C, training):
@@ -93,7 +97,7 @@ class _Plan:
         gi = self.new(T * B, 2048)
         for d, sfx in enumerate(["", "_reverse"]):
             L.gemm(x, P[r + "weight_ih_l0" + sfx], gi[:, d * 1024:], P[r + "bias_ih_l0" + sfx], T * B, 1024, I, I, 1, I, 1, 2048, 1, 0, 0, 0,
-                   0, 0, 1, None)
+                   0, self.pf, 1, None)
         h = torch.zeros(2, 2, B, 256, device=self.dev)               # ping-pong [buf][dir][B][256]
         c = torch.zeros(2, 2, B, 256, device=self.dev)
         rec = self.new(T * B, 512)
@@ -142,7 +146,7 @@ class _Plan:
         p5 = x.view(B, 2, W, 512)
         cols = torch.stack([p5[:, dy, dx:dx + T, :] for dy in (0, 1) for dx in (0, 1)], dim=-1).reshape(B * T, 2048)
         c6 = self.new(B * T, 512)
-        L.gemm(cols, P["cnn.conv6.weight"], c6, P["cnn.conv6.bias"], B * T, 512, 2048, 2048, 1, 2048, 1, 512, 1, 0, 0, 0, 0, 0, 1, None)
+        L.gemm(cols, P["cnn.conv6.weight"], c6, P["cnn.conv6.bias"], B * T, 512, 2048, 2048, 1, 2048, 1, 512, 1, 0, 0, 0, 0, self.pf, 1, None)
         feat, stat6 = self.bn_relu(P, 6, c6, B * T, 512, training)                  # rows (b, t)
         featT = feat.view(B, T, 512).transpose(0, 1).contiguous().view(T * B, 512)   # time-major rows (t, b)
         rec0, sv0 = self.bilstm(P, "rnn.0.", featT, 512, T, B, want_ctx)
@@ -183,7 +187,7 @@ class _Plan:
     def dw(self, dy, lddy, x, ldx, dW, R, N, K):
         """dW[N,K] += dy[R,N]^T x[R,K]"""
         sk = self.splitk(N, K, R)
-        self.L.gemm(dy, x, dW, None, N, K, R, 1, lddy, 1, ldx, K, 1, 0, 0, 0, 1, 0, sk, self.ws if sk > 1 else None)
+        self.L.gemm(dy, x, dW, None, N, K, R, 1, lddy, 1, ldx, K, 1, 0, 0, 0, 1, self.pf, sk, self.ws if sk > 1 else None)
 
     def bilstm_bwd(self, P, pre, drec, sv, X, I, rec, T, B, G):
         """BPTT of one BidirectionalLSTM's nn.LSTM: returns dX [T*B, I] (time-major); accumulates the eight parameter grads."""
@@ -206,7 +210,7 @@ class _Plan:
             self.dw(g, 2048, X, I, G[r + "weight_ih_l0" + sfx], T * B, 1024, I)
             L.colsum(g, 2048, T * B, 1024, G[r + "bias_ih_l0" + sfx], 1, self.ws)
             L.colsum(g, 2048, T * B, 1024, G[r + "bias_hh_l0" + sfx], 1, self.ws)
-            L.gemm(g, P[r + "weight_ih_l0" + sfx], dX, None, T * B, I, 1024, 2048, 1, 1, I, I, 1, 0, 0, 0, d, 0, 1, None)
+            L.gemm(g, P[r + "weight_ih_l0" + sfx], dX, None, T * B, I, 1024, 2048, 1, 1, I, I, 1, 0, 0, 0, d, self.pf, 1, None)
         return dX
 
     def conv3_bwd(self, P, i, x, dc, B, H, W, Cin, Cout, wd, G, need_dx=True):
@@ -222,12 +226,12 @@ class _Plan:
         sk = max(1, min((B * H * W) // 256, -(-1024 // tiles)))
         while sk > 1 and Cout * T9 * Cin * sk > WS_FLOATS:
             sk //= 2
-        L.conv_wgrad(x, dc, G[f"cnn.conv{i}.weight"], B, H, W, Cin, Cout, 3, 3, Cin, Cout, sk, self.ws, 1)
+        L.conv_wgrad(x, dc, G[f"cnn.conv{i}.weight"], B, H, W, Cin, Cout, 3, 3, Cin, Cout, sk, self.ws, 1 | self.pf)
         L.colsum(dc, Cout, B * H * W, Cout, G[f"cnn.conv{i}.bias"], 1, self.ws)
         if not need_dx:
             return None
         dx = self.new(B * H * W, Cin)
-        L.conv_fwd(dc, wd, None, dx, B, H, W, Cout, Cin, 3, 3, Cout, Cin, 9 * Cout, 1, 0, Cout, 0, 0)
+        L.conv_fwd(dc, wd, None, dx, B, H, W, Cout, Cin, 3, 3, Cout, Cin, 9 * Cout, 1, 0, Cout, 0, self.pf)
         return dx
 
     def backward(self, ctx, dlogits, G):
@@ -253,7 +257,7 @@ class _Plan:
         for dy in (0, 1):
             for dxx in (0, 1):                       # dP[b, dy, t+dx, ci] += sum_co dc6[b, t, co] W[co, ci, dy, dx]
                 L.gemm(dc6, w6[dy * 2 + dxx:], dx.view(-1)[(dy * W5 + dxx) * 512:], None, T, 512, 512, 512, 1, 4, 2048, 512, B,
-                       T * 512, 0, 2 * W5 * 512, 1, 0, 1, None)
+                       T * 512, 0, 2 * W5 * 512, 1, self.pf, 1, None)
         dx = dx.view(B * 2 * W5, 512)
         # the 3x3 trunk, last layer first
         acts = ctx["acts"]
@@ -325,6 +329,7 @@ class CRNN(nn.Module):
         self.cnn = cnn
         self.rnn = nn.Sequential(BidirectionalLSTM(512, nh, nh), BidirectionalLSTM(nh, nh, nclass))
         self.nclass = nclass
+        self.matmul_precision = "fp32"               # or "bf16": see tatt_amd.model.tsrn.TSRN_TL_TRANS.matmul_precision
         self._plan = None
 
     def plan(self):

@@ -113,6 +113,9 @@ class TSRN_TL_TRANS(nn.Module):
         # dropout control of the HIP path: p follows the reference (0.1) in training; the seed advances per call
         self.dropout_p = 0.1
         self.dropout_seed = 0
+        # matrix-core precision of this model's GEMM / convolution launches: "fp32" (exact, the parity path) or "bf16" (operands
+        # rounded to bf16, fp32 accumulate; the STN head, TPS and the recurrent positional encoding stay fp32) -- BASELINE config 3
+        self.matmul_precision = "fp32"
         self._engine = None
 
     # ------------------------------------------------------------------------------------------------

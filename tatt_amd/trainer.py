@@ -6,6 +6,14 @@ gradients (tail -> SRBs -> TP interpreter -> block1/STN), so that data-parallel 
 contiguous buckets over RCCL while the rest of the backward pass is still running, and the fused
 clip+Adam kernel touches every parameter once.  Every nn.Parameter of the module stays a view of the flat
 buffer (state_dict / checkpoints are unaffected).
+
+Data parallel + hipGraph: the step is captured as THREE graphs cut at the bucket boundaries of the backward pass
+(forward + tail | SRBs | TP interpreter + block1/STN) plus one for clip+Adam; between two replays the finished
+bucket's all-reduce is issued on RCCL's own stream, so it is in flight while the next segment runs -- the same
+overlap the eager path gets from Engine.backward(on_stage=...), and bit-identical to it.  How much can overlap is
+bounded by the network: the recurrent positional encoding's weights (19.6 MB of the 30.4 MB) and the STN head
+(7.4 MB) are the LAST gradients the backward pass produces, so only the tail and SRB buckets (3.3 MB) travel
+under cover; the rest is exposed (reported by bench.py as allreduce_ms_exposed).
 """
 from __future__ import annotations
 
@@ -54,6 +62,31 @@ def allreduce_mean(t, async_op=False):
     return None
 
 
+def replica_fingerprint(t):
+    """(sum, sum of squares, bit-pattern checksum) of a flat fp32 buffer as three float64 values: equal on every rank iff the
+    replicas hold bit-identical parameters (up to a 2^-53-ish chance for the sums, none for the integer checksum below 2^53)."""
+    bits = t.detach().contiguous().view(torch.int32).to(torch.int64)
+    w = torch.arange(1, bits.numel() + 1, device=t.device, dtype=torch.int64) % 8191 + 1      # position-dependent weights
+    chk = int(((bits & 0xFFFF) * w).sum().item() % (1 << 52))
+    d = t.detach().double()
+    return torch.tensor([d.sum().item(), (d * d).sum().item(), float(chk)], dtype=torch.float64, device=t.device)
+
+
+def assert_replicas_identical(t, what="parameters"):
+    """Data-parallel self-check: every rank must hold the same `t`.  All-gathers replica_fingerprint(t) and raises on EVERY rank
+    if any differs (the reference precedent, DistributedDataParallel, verifies parameter shapes only; here the values are
+    checked because the replicas are kept in step by construction, not by a framework).  Returns the number of ranks seen."""
+    fp = replica_fingerprint(t)
+    world = dist.get_world_size()
+    allfp = [torch.zeros_like(fp) for _ in range(world)]
+    dist.all_gather(allfp, fp)
+    bad = [r for r in range(world) if not torch.equal(allfp[r], allfp[0])]
+    if bad:
+        raise RuntimeError(f"data-parallel replicas diverged: {what} on ranks {bad} differ from rank 0 "
+                           f"(fingerprints {[f.tolist() for f in allfp]})")
+    return world
+
+
 class SRTrainer:
     def __init__(self, model, lr=1e-3, betas=(0.5, 0.999), eps=1e-8, max_norm=0.25, loss_weight=(1.0, 1e-4),
                  use_graph=False, distributed=None, tsc=False, tssim_rotation_degree=10.0, training_stablize=False):
@@ -94,10 +127,13 @@ class SRTrainer:
         self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int32)
         self.eng.seed_dev = self.seed_dev
         self.use_graph = use_graph
-        self.graph = None
+        self.graph = None                                     # list of captured segments (one entry without a process group)
+        self.graph_update = None                              # data parallel: clip+Adam, replayed after the all-reduces
         self.static = None
         self.per = None
         self.steps = 0
+        self.time_comm = False                                # bench.py: bracket the exposed all-reduce wait with events
+        self.comm_events = []
 
     # ------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -108,7 +144,9 @@ class SRTrainer:
         start = torch.argsort(per)[int(keep_proportion * B)]
         return (torch.arange(B, device=per.device) < start).to(per.dtype)
 
-    def _fwd_bwd(self, lr_img, hr_img, tp, overlap, arc=None, tp_ready=None):
+    def _fwd_bwd(self, lr_img, hr_img, tp, overlap, arc=None, tp_ready=None, on_stage=None):
+        """overlap: issue each gradient bucket's all-reduce from inside the backward pass (eager data parallel); on_stage: called
+        instead at the same points (graph capture cuts its segments there)."""
         L, B = self.L, lr_img.shape[0]
         self.flat_g.zero_()
         L.seed_bump(self.seed_dev)
@@ -140,13 +178,16 @@ class SRTrainer:
             L.rotate_bwd(arc, g_rot, dsr, B, C, H, W)                                # += onto the image-loss gradient
             self.eng.backward(ctx2, g_sr2, self.G)
         works = []
+        cut = on_stage
 
         def on_stage(name):
             if overlap:
                 a, b = self.bucket_range[BUCKETS.index(name)]
                 works.append(allreduce_mean(self.flat_g[a:b], async_op=True))
+            elif cut is not None:
+                cut(name)
 
-        self.eng.backward(ctx, dsr, self.G, on_stage=on_stage)
+        self.eng.backward(ctx, dsr, self.G, on_stage=on_stage if (overlap or cut is not None) else None)
         return per, works
 
     def ws_ssim(self, n):
@@ -167,60 +208,152 @@ class SRTrainer:
         self.L.clip_adam(self.flat_p, self.flat_g, self.m, self.v, self.n, self.lr, self.betas[0], self.betas[1], self.eps,
                          self.max_norm, self.state, self.ws)
 
+    def verify_replicas(self):
+        """Raise unless every rank holds bit-identical parameters and optimiser moments; returns the rank count RCCL reports
+        through a collective (1 without a process group)."""
+        if not self.dp:
+            return 1
+        n = assert_replicas_identical(self.flat_p, "SR parameters")
+        assert_replicas_identical(self.m, "Adam first moments")
+        return n
+
+    def stateful_buffers(self):
+        """Buffers a forward pass updates in place (BatchNorm running statistics and counters)."""
+        return [b for n, b in self.model.named_buffers() if "running_" in n or n.endswith("num_batches_tracked")]
+
+    def _bucket_views(self, name):
+        a, b = self.bucket_range[BUCKETS.index(name)]
+        return [self.flat_g[a:b]]
+
+    def _wait_all(self, works):
+        """Make the current stream wait for the collectives (no host block); with time_comm the wait is bracketed by events:
+        what it takes is the part of the all-reduce time that the backward pass did not cover."""
+        e0 = e1 = None
+        if self.time_comm:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for w in works:
+            if w is not None:
+                w.wait()
+        if self.time_comm:
+            e1.record()
+            self.comm_events.append((e0, e1))
+
+    def exposed_comm_ms(self):
+        """Mean over the recorded steps of the un-overlapped all-reduce wait (call after a device synchronisation)."""
+        ms = [a.elapsed_time(b) for a, b in self.comm_events]
+        self.comm_events = []
+        return sum(ms) / len(ms) if ms else 0.0
+
+    @staticmethod
+    def _is_capture_error(e):
+        msg = str(e).lower()
+        return isinstance(e, RuntimeError) and ("captur" in msg or "graph" in msg) and "fault" not in msg and "illegal" not in msg
+
+    def _capture(self, lr_img, hr_img, tp, arc):
+        """Warm up once outside capture (allocator, lazy code-object loads) with every side effect undone, then capture the step:
+        one graph without a process group; with one, segments cut where a gradient bucket is complete (module docstring)."""
+        self.static = [lr_img.clone(), hr_img.clone(), tp.clone()] + ([arc.clone()] if self.tsc else [])
+        args = dict(arc=self.static[3] if self.tsc else None)
+        bufs = self.stateful_buffers()
+        snap = [b.clone() for b in bufs]                  # the warm-up pass must not count as a training step: BatchNorm running
+        s = torch.cuda.Stream()                           # statistics / num_batches_tracked are put back, like the dropout seed
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._fwd_bwd(*self.static[:3], overlap=False, **args)
+        torch.cuda.current_stream().wait_stream(s)
+        for b, v in zip(bufs, snap):
+            b.copy_(v)
+        self.seed_dev.zero_()
+        # thread_local: RCCL's watchdog thread polls events of earlier collectives (the parameter broadcast, the previous
+        # step's all-reduce); under the default global mode such a poll from ANOTHER thread during capture aborts the
+        # process (seen once in tests/test_gpu_dp.py when the capture began right after an eager data-parallel step)
+        torch.cuda.synchronize()
+        graphs, pool, cur = [], torch.cuda.graph_pool_handle(), [None]
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            cm = torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local")
+            cm.__enter__()
+            cur[0] = (g, cm)
+
+        def end(buckets):
+            g, cm = cur[0]
+            cm.__exit__(None, None, None)
+            graphs.append((g, buckets))
+            cur[0] = None
+
+        def cut(name):                                    # Engine.backward has joined its weight-gradient streams here
+            if name in ("tail", "srbs"):
+                end([name])
+                begin()
+        try:
+            begin()
+            self.per, _ = self._fwd_bwd(*self.static[:3], overlap=False, on_stage=cut if self.dp else None, **args)
+            if self.dp:
+                end(["infogen", "head", "extra"])
+                begin()
+            self._update()
+            end([])
+        except Exception:
+            if cur[0] is not None:
+                try:
+                    cur[0][1].__exit__(None, None, None)
+                except Exception:
+                    pass
+            raise
+        self.graph = graphs[:-1] if self.dp else graphs
+        self.graph_update = graphs[-1][0] if self.dp else None
+
+    def _reset_streams(self):
+        self.eng.reset_streams()
+
     def step(self, lr_img, hr_img, tp, arc=None):
         """One optimisation step; returns the per-sample ImageLoss [B] (device tensor, no host sync).  With tsc=True
         `arc` [B] are the rotation angles in radians (drawn like the reference when omitted); the TRI_SSIM value of
         the step is left in `self.tssim` (device scalar)."""
         self.model.train()
-        hr_img = hr_img.contiguous().float()
+        # the kernels read raw fp32 memory: normalise every input once, for the eager and the captured path alike (a sliced,
+        # channels_last or half-precision batch would otherwise be misread by the TSC rotation / the student's input transform)
+        lr_img = lr_img.detach().contiguous().float()
+        hr_img = hr_img.detach().contiguous().float()
+        if tp is not None:
+            tp = tp.detach().float()                          # the [B,K,1,26] view of the recogniser's softmax: read through its strides
         if self.tsc:
             arc = (self.sample_arc(lr_img.shape[0]) if arc is None else arc).to(device=lr_img.device, dtype=torch.float32)
         if not self.use_graph:
             per, works = self._fwd_bwd(lr_img, hr_img, tp, overlap=self.dp, arc=arc)
-            for w in works:
-                if w is not None:
-                    w.wait()
+            self._wait_all(works)
             self._update()
             self.steps += 1
             return per
-        # hipGraph path: forward+backward (+ optimiser when single-GPU) captured once, replayed per step
+        # hipGraph path: the step captured once, replayed per step
         if self.graph is None:
-            self.static = [lr_img.clone().contiguous(), hr_img.clone(), tp.clone()] + ([arc.clone()] if self.tsc else [])
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):                       # warm-up outside capture (allocator, lazy module loads)
-                self._fwd_bwd(*self.static[:3], overlap=False, arc=self.static[3] if self.tsc else None)
-            torch.cuda.current_stream().wait_stream(s)
-            self.seed_dev.zero_()
-            # the warm-up touched BatchNorm running stats: harmless for a benchmark, noted for training use
-            self.graph = torch.cuda.CUDAGraph()
-            # thread_local: RCCL's watchdog thread polls events of earlier collectives (the parameter broadcast, the previous
-            # step's all-reduce); under the default global mode such a poll from ANOTHER thread during capture aborts the
-            # process (seen once in tests/test_gpu_dp.py when the capture began right after an eager data-parallel step)
-            if self.dp:
-                torch.cuda.synchronize()
             try:
-                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                    self.per, _ = self._fwd_bwd(*self.static[:3], overlap=False, arc=self.static[3] if self.tsc else None)
-                    if not self.dp:
-                        self._update()
-            except Exception as e:                            # keep training: same step, launched eagerly (and say so loudly)
+                self._capture(lr_img, hr_img, tp, arc)
+            except Exception as e:
+                if not self._is_capture_error(e):             # a kernel fault or an argument error is not a capture problem
+                    raise
                 import sys
                 print(f"tatt_amd: hipGraph capture of the training step failed ({type(e).__name__}: {e}); continuing with eager "
-                      "launches", file=sys.stderr, flush=True)
-                self.use_graph, self.graph = False, None
+                      "launches on fresh streams", file=sys.stderr, flush=True)
+                self.use_graph, self.graph, self.graph_update = False, None, None
                 torch.cuda.synchronize()
+                self._reset_streams()
                 return self.step(lr_img, hr_img, tp, arc=arc)
         for dst, src in zip(self.static, (lr_img, hr_img, tp) + ((arc,) if self.tsc else ())):
             dst.copy_(src)
-        self.graph.replay()
-        if self.dp:
-            works = [allreduce_mean(self.flat_g[a:b], async_op=True) for a, b in self.bucket_range]
-            works += [allreduce_mean(t, async_op=True) for t in self.extra_grad_buffers()]
-            for w in works:
-                if w is not None:
-                    w.wait()
-            self._update()
+        if not self.dp:
+            self.graph[0][0].replay()
+        else:
+            works = []
+            for g, buckets in self.graph:                     # segment k+1 runs while bucket k is on the wire
+                g.replay()
+                for name in buckets:
+                    views = self.extra_grad_buffers() if name == "extra" else self._bucket_views(name)
+                    works += [allreduce_mean(t, async_op=True) for t in views]
+            self._wait_all(works)
+            self.graph_update.replay()
         self.steps += 1
         return self.per
 
@@ -263,7 +396,15 @@ class TATTTrainer(SRTrainer):
                 dist.broadcast(b, 0)
         self.loss_tp = None                                    # device scalar: SemanticLoss of the last step (L_TP = 100 x)
 
-    def _fwd_bwd(self, lr_img, hr_img, tp, overlap, arc=None):
+    def stateful_buffers(self):
+        return super().stateful_buffers() + [b for n, b in self.student.named_buffers()
+                                             if "running_" in n or n.endswith("num_batches_tracked")]
+
+    def _reset_streams(self):
+        super()._reset_streams()
+        self._tp_stream = self._st_stream = None
+
+    def _fwd_bwd(self, lr_img, hr_img, tp, overlap, arc=None, on_stage=None):
         """`tp` is ignored: the prior comes from the student CRNN."""
         L, B = self.L, lr_img.shape[0]
         K = self.student.nclass
@@ -303,14 +444,32 @@ class TATTTrainer(SRTrainer):
             ws = torch.empty(L.semantic_loss_workspace(T * B), device=lr_img.device)
             L.semantic_loss(logits_s, logits_t, self.loss_tp, dz, 100.0, T * B, K, ws)
             plan.backward(ctx_s, dz.view(T, B, K), self.G_s)
-        per, works = super()._fwd_bwd(lr_img, hr_img, prior, overlap, arc=arc, tp_ready=tp_ready)
-        main.wait_stream(side)
+        if on_stage is not None:
+            # segmented capture (data parallel + hipGraph): every forked stream must be back on the capturing stream when a
+            # segment ends, so the L_TP / student strand is joined before the first cut instead of at the end of the step
+            # (once: in a later segment `side` is not part of the capture, and a capturing stream may not wait on outside work)
+            cut, joined = on_stage, []
+
+            def on_stage(name):
+                if not joined:
+                    main.wait_stream(side)
+                    joined.append(True)
+                cut(name)
+        per, works = super()._fwd_bwd(lr_img, hr_img, prior, overlap, arc=arc, tp_ready=tp_ready, on_stage=on_stage)
+        if on_stage is None:
+            main.wait_stream(side)
         if overlap:
             works.append(allreduce_mean(self.s_g, async_op=True))
         return per, works
 
     def extra_grad_buffers(self):
         return [self.s_g]
+
+    def verify_replicas(self):
+        n = super().verify_replicas()
+        if self.dp:
+            assert_replicas_identical(self.s_p, "student CRNN parameters")
+        return n
 
     def _update(self):
         super()._update()

@@ -24,7 +24,9 @@ sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
 sys.path.insert(0, "/root/reference")
 
 from model import tsrn as ref_tsrn                      # noqa: E402
+from model import torch_distortion                      # noqa: E402  (model/__init__.py:4-30)
 from loss.image_loss import ImageLoss                   # noqa: E402
+from loss.semantic_loss import SemanticLoss             # noqa: E402
 from utils import ssim_psnr                             # noqa: E402
 from oracle import procgen                              # noqa: E402
 
@@ -61,32 +63,41 @@ def build(K):
 
 
 def rotate_ref(img, arc):
-    """Call-compatible restatement of the TextSR.torch_rotate_img *call* (a method of a class that
-    cannot be imported here) through the identical stock ops F.affine_grid/F.grid_sample."""
-    import torch.nn.functional as F
-    N, C, H, W = img.shape
-    r = H / float(W)
-    a = torch.stack([torch.cos(arc), torch.sin(arc) * r, torch.zeros_like(arc),
-                     -torch.sin(arc) / r, torch.cos(arc), torch.zeros_like(arc)], 1).reshape(N, 2, 3)
-    return F.grid_sample(img, F.affine_grid(a, img.shape))
+    """TextSR.torch_rotate_img(img, arc) (interfaces/super_resolution_eng.py:50-82, a method of a class that cannot be
+    imported here) through the reference's own importable twin model.torch_distortion (model/__init__.py:4-30):
+    with rand_offs = 0.5 its ratios_mul = ratios + 0.5*0.2*2 - 0.2 equals ratios, i.e. the rand_offs=None branch."""
+    return torch_distortion(img, arc.to(img.dtype), torch.full_like(arc, 0.5, dtype=img.dtype))
 
 
-def case(K, B, train):
+def rot_arcs(B, seed=0, deg=10.0):
+    """angle_batch of the TSC term / config 4's pre-deformation: U(-deg, deg) per sample, radians (procedural)."""
+    r = np.random.default_rng([B, seed, 77])
+    return torch.from_numpy(((r.random(B) * 2 - 1) * deg / 180.0 * np.pi).astype(np.float32))
+
+
+def case(K, B, train, rot=False):
     """fp32 pass of the reference (keys as is) + fp64 pass of the same modules (keys prefixed 'f64/'): the fp64
     run is the reference algorithm without fp32 rounding noise, which for some gradients (init_factor, PReLU
     slopes, STN head at tiny batch) is as large as 5e-3 relative in the reference's own fp32 run."""
-    out = _case(K, B, train, torch.float32)
+    out = _case(K, B, train, torch.float32, rot)
     if train:
-        for k, v in _case(K, B, train, torch.float64).items():
-            if k.startswith(("sr", "grad", "image_loss", "loss", "ctrl_points", "tp_map", "query_pos", "pre_sigmoid")):
+        for k, v in _case(K, B, train, torch.float64, rot).items():
+            if k.startswith(("sr", "grad", "image_loss", "loss", "ctrl_points", "tps_out", "tp_map", "query_pos", "pre_sigmoid")):
                 out["f64/" + k] = v
     return out
 
 
-def _case(K, B, train, dtype):
+def _case(K, B, train, dtype, rot=False):
+    """rot: BASELINE config 4 -- the LR/HR pair is pre-deformed by the reference's rotation (+-10 degrees) before the step, so
+    that the STN head / TPS rectification see rotated text."""
     out = {}
     m = build(K).to(dtype)
     hr, lr, tp = [t.to(dtype) for t in procgen.make_inputs(B, K, seed=0)]
+    if rot:
+        arc = rot_arcs(B)
+        out["arc"] = arc.numpy()
+        lr, hr = rotate_ref(lr, arc), rotate_ref(hr, arc)
+        put(out, "rot_lr", lr, full=(B <= 4))
     inter = {}
     hooks = []
 
@@ -161,17 +172,34 @@ def losses():
     out["tri_ssim"] = np.array(ssim_psnr.TRI_SSIM()(sr, sr2, hr).item())
     out["ssim"] = np.array(ssim_psnr.SSIM()(sr, hr).item())
     out["psnr"] = np.array(float(ssim_psnr.calculate_psnr(sr, hr)))
+    # SemanticLoss (loss/semantic_loss.py:21-38) on two softmaxed [26, B, 37] priors, value and gradient wrt the prediction
+    g2 = torch.Generator().manual_seed(9)
+    pred = torch.softmax(2.0 * torch.randn(26, B, 37, generator=g2), -1).requires_grad_(True)
+    gt = torch.softmax(2.0 * torch.randn(26, B, 37, generator=g2), -1)
+    sl = SemanticLoss()(pred, gt)
+    sl.backward()
+    out["sem_pred"], out["sem_gt"] = pred.detach().numpy(), gt.numpy()
+    out["sem_loss"], out["sem_dpred"] = np.array(sl.item()), pred.grad.numpy()
     return out
 
 
+CASES = [(37, 1, False, False), (37, 2, False, False), (37, 5, False, False), (37, 2, True, False), (37, 5, True, False),
+         (2448, 2, True, False),
+         (37, 64, True, False),         # BASELINE config 2 at its own size: 64-step RPE chain, well-conditioned train-mode BN
+         (37, 4, True, True), (37, 64, True, True)]   # BASELINE config 4: STN/TPS on inputs pre-rotated by +-10 degrees
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for K, B, train in [(37, 1, False), (37, 2, False), (37, 5, False), (37, 2, True),
-                        (37, 5, True), (2448, 2, True)]:
-        o = case(K, B, train)
-        fn = os.path.join(HERE, f"tsrn_K{K}_B{B}_{'train' if train else 'eval'}.npz")
+    only = sys.argv[1:]                                  # e.g. `make_golden.py tsrn_K37_B64_train losses` regenerates those only
+    for K, B, train, rot in CASES:
+        name = f"tsrn_K{K}_B{B}_{'rot_' if rot else ''}{'train' if train else 'eval'}"
+        if only and name not in only:
+            continue
+        o = case(K, B, train, rot)
+        fn = os.path.join(HERE, name + ".npz")
         np.savez_compressed(fn, **o)
         print(fn, os.path.getsize(fn) // 1024, "KiB")
-    fn = os.path.join(HERE, "losses.npz")
-    np.savez_compressed(fn, **losses())
-    print(fn, os.path.getsize(fn) // 1024, "KiB")
+    if not only or "losses" in only:
+        fn = os.path.join(HERE, "losses.npz")
+        np.savez_compressed(fn, **losses())
+        print(fn, os.path.getsize(fn) // 1024, "KiB")

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tatt_amd.trainer import BUCKETS, allreduce_mean, plan_flat_layout
+from tatt_amd.trainer import BUCKETS, allreduce_mean, assert_replicas_identical, plan_flat_layout
 
 
 def _shapes():
@@ -47,6 +47,16 @@ def _worker(rank, world, port, q):
         allreduce_mean(flat[a:b], async_op=True)
     other = torch.randn(total, generator=torch.Generator().manual_seed(100 + (1 - rank)))
     ok = torch.allclose(flat, (mine + other) / 2, atol=1e-6)
+    # the replica self-check bench.py runs after its timed steps: passes on the (now identical) reduced buffer, raises on
+    # EVERY rank when one replica differs in a single low bit
+    ok = ok and assert_replicas_identical(flat) == world
+    if rank == 1:
+        flat.view(torch.int32)[12345] ^= 1
+    try:
+        assert_replicas_identical(flat)
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "diverged" in str(e)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -1,4 +1,4 @@
-"""bf16 matrix-core mode (tatt_set_matmul_precision(1); BASELINE config 3): operands rounded to bf16 (nearest-even), fp32
+"""bf16 matrix-core mode (the TATT_BF16 flag of the GEMM / convolution entry points, model.matmul_precision = "bf16"; BASELINE config 3): operands rounded to bf16 (nearest-even), fp32
 accumulate.  Kernel-level: exact in the sense that the result equals the fp64 product of the bf16-ROUNDED operands to fp32
 accumulation accuracy (5e-6 rel-L2).  Model-level: the tolerances SURVEY §8c proposes for bf16 (output max-abs <= 1e-2,
 rel-L2 <= 1e-2, gradient cosine >= 0.999) against the fp64 oracle."""
@@ -19,12 +19,7 @@ def L():
     return lib()
 
 
-@pytest.fixture(autouse=True)
-def bf16_mode():
-    L().set_matmul_precision(1)
-    assert L().get_matmul_precision() == 1
-    yield
-    L().set_matmul_precision(0)
+BF16 = 2          # TATT_BF16 (include/tatt_hip.h): a per-call flag, the library keeps no precision state
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -48,17 +43,17 @@ def ws(n=8 << 20):
 def test_gemm_all_layouts(M, N, K):
     A, B_, bias = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2)
     out = torch.empty(M, N, device="cuda")
-    L().gemm(A.cuda(), B_.cuda(), out, bias.cuda(), M, N, K, K, 1, K, 1, N, 1, 0, 0, 0, 0, 0, 1, None)            # NT
+    L().gemm(A.cuda(), B_.cuda(), out, bias.cuda(), M, N, K, K, 1, K, 1, N, 1, 0, 0, 0, 0, BF16, 1, None)         # NT
     ref = r16(A) @ r16(B_).t() + bias.double()
     close(out, ref, 5e-6, "nt (bf16-rounded operands)")
     assert rel_l2(out.cpu().double().numpy(), (A.double() @ B_.double().t() + bias.double()).numpy()) > 1e-4   # it IS bf16
     Bt = B_.t().contiguous()                                                                                    # NN: B row-contiguous
-    L().gemm(A.cuda(), Bt.cuda(), out, None, M, N, K, K, 1, 1, N, N, 1, 0, 0, 0, 0, 0, 1, None)
+    L().gemm(A.cuda(), Bt.cuda(), out, None, M, N, K, K, 1, 1, N, N, 1, 0, 0, 0, 0, BF16, 1, None)
     close(out, r16(A) @ r16(B_).t(), 5e-6, "nn")
     At = A.t().contiguous()                                                                                     # TN, split-K
-    L().gemm(At.cuda(), B_.cuda(), out, None, M, N, K, 1, M, K, 1, N, 1, 0, 0, 0, 0, 0, 2, ws())
+    L().gemm(At.cuda(), B_.cuda(), out, None, M, N, K, 1, M, K, 1, N, 1, 0, 0, 0, 0, BF16, 2, ws())
     close(out, r16(A) @ r16(B_).t(), 5e-6, "tn split-K")
-    L().gemm(At.cuda(), Bt.cuda(), out, None, M, N, K, 1, M, 1, N, N, 1, 0, 0, 0, 0, 0, 1, None)                # TT
+    L().gemm(At.cuda(), Bt.cuda(), out, None, M, N, K, 1, M, 1, N, N, 1, 0, 0, 0, 0, BF16, 1, None)             # TT
     close(out, r16(A) @ r16(B_).t(), 5e-6, "tt")
 
 
@@ -74,13 +69,13 @@ def test_conv_fwd_dgrad_wgrad(B, H, W, Cin, Cout, k):
     wf, wd = torch.empty(w.numel(), device="cuda"), torch.empty(w.numel(), device="cuda")
     L().conv_pack_w(w.cuda(), wf, wd, Cout, Cin, k, k)
     out, dx = torch.empty(B, H, W, Cout, device="cuda"), torch.empty(B, H, W, Cin, device="cuda")
-    L().conv_fwd(xn, wf, b.cuda(), out, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, 0, 0)
+    L().conv_fwd(xn, wf, b.cuda(), out, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, 0, BF16)
     close(out.permute(0, 3, 1, 2), y, 5e-6, "fwd")
     if Cout % 32 == 0:                                       # the 64 -> 4 convolution's dgrad runs on the skinny kernels (fp32)
-        L().conv_fwd(dyn, wd, None, dx, B, H, W, Cout, Cin, k, k, Cout, Cin, T * Cout, 1, 0, Cout, 0, 0)
+        L().conv_fwd(dyn, wd, None, dx, B, H, W, Cout, Cin, k, k, Cout, Cin, T * Cout, 1, 0, Cout, 0, BF16)
         close(dx.permute(0, 3, 1, 2), gx, 5e-6, "dgrad")
     dW = torch.zeros(Cout, Cin, k, k, device="cuda")
-    L().conv_wgrad(xn, dyn, dW, B, H, W, Cin, Cout, k, k, Cin, Cout, 4, ws(), 1)
+    L().conv_wgrad(xn, dyn, dW, B, H, W, Cin, Cout, k, k, Cin, Cout, 4, ws(), 1 | BF16)
     close(dW, gw, 5e-6, "wgrad")
 
 
@@ -99,6 +94,7 @@ def test_model_forward_backward_within_bf16_tolerance():
     m = TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=True, srb_nums=5, mask=True, hidden_units=32)
     m.load_state_dict(P, strict=True)
     m = m.cuda().train()
+    m.matmul_precision = "bf16"
     m.dropout_p = 0.0                                         # parity is defined with dropout off
     sr = m(lr.cuda(), tp.cuda())
     from tatt_amd.loss.image_loss import ImageLoss

@@ -120,3 +120,16 @@ def test_semantic_loss_fused_softmax():
     assert rel_l2(dz.cpu().double().numpy(), a.grad.numpy()) < 1e-4
     L.semantic_loss(zs.cuda(), zt.cuda(), out, None, 0.0, R_, K, ws)      # forward only
     assert abs(out.item() - ref.item()) < 1e-6 + 1e-5 * abs(ref.item())
+
+
+def test_semantic_loss_module_vs_reference_golden():
+    """tatt_amd.loss.SemanticLoss (tatt_semantic_loss_probs) against a value and gradient produced by the reference's own
+    loss/semantic_loss.py:21-38 (tests/golden/make_golden.py, losses.npz: sem_*)."""
+    from tatt_amd.loss import SemanticLoss
+    from tests.util import load_golden
+    g = load_golden("losses.npz")
+    pred = torch.from_numpy(g["sem_pred"]).cuda().requires_grad_(True)
+    loss = SemanticLoss()(pred, torch.from_numpy(g["sem_gt"]).cuda())
+    loss.backward()
+    assert abs(loss.item() - float(g["sem_loss"])) < 1e-5 * abs(float(g["sem_loss"]))
+    assert rel_l2(pred.grad.cpu().double().numpy(), g["sem_dpred"]) < 1e-4

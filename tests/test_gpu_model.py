@@ -52,6 +52,82 @@ def test_eval_forward_vs_reference_golden(B):
         check_against(g, k, st[k], 2e-5)
 
 
+def stn_scale(n):
+    """B=64 gradient pins: the STN head (ReLU / max-pool decisions, x64 pixel scaling) gets 4x the tolerance of everything else."""
+    return 4.0 if n.startswith("stn_head.") else 1.0
+
+
+@pytest.mark.parametrize("rot", [False, True])
+def test_config2_and_config4_at_B64_vs_reference_golden(rot):
+    """BASELINE config 2 at its own size -- B = 64, train mode -- against goldens made by the real reference (fp32 and fp64 runs):
+    output, every stage incl. the 64-step recurrent positional encoding (its chain length IS the batch size), control
+    points, per-sample loss, all 231 gradient norms, twelve full gradients, BatchNorm statistics.  At this batch the train-mode
+    BatchNorms are well conditioned, so this is the tight train-mode gradient pin: 1.5e-3 of the reference's fp64 run (STN head,
+    whose ReLU / max-pool decisions and x64 pixel scaling amplify fp32 rounding, 6e-3).  rot = BASELINE config 4: the same
+    with LR / HR pre-deformed by the reference's own rotation (model/__init__.py:4-30, +-10 degrees) through tatt_rotate_fwd,
+    asserting the rotated input, control points and the TPS-rectified image."""
+    B, K = 64, 37
+    g = load_golden(f"tsrn_K37_B64_{'rot_' if rot else ''}train.npz")
+    m = build(K).train()
+    m.dropout_p = 0.0
+    hr, lr, tp = [t.cuda() for t in procgen.make_inputs(B, K, seed=0)]
+    eng = m.engine()
+    if rot:
+        arc = torch.from_numpy(g["arc"]).cuda()
+        d_lr, d_hr = torch.empty_like(lr), torch.empty_like(hr)
+        eng.L.rotate_fwd(lr, arc, d_lr, B, 4, 16, 64)
+        eng.L.rotate_fwd(hr, arc, d_hr, B, 4, 32, 128)
+        lr, hr = d_lr, d_hr
+        check_against(g, "rot_lr", lr, 2e-6)
+    sr, ctx = eng.forward(lr, tp, True, 0, p_drop=0.0)
+    st = stages(ctx, B)
+    check_against(g, "ctrl_points", ctx["stn"][5].view(B, 20, 2), 2e-5)
+    check_against(g, "f64/ctrl_points", ctx["stn"][5].view(B, 20, 2), 2e-5)
+    check_against(g, "tps_out", nchw(ctx["xs"], B), STAGE_TOL)
+    check_against(g, "f64/tps_out", nchw(ctx["xs"], B), STAGE_TOL)
+    for k in ["block1", "query_pos", "memory", "tp_map", "block2", "block4", "block6", "pre_sigmoid"]:
+        check_against(g, k, st[k], STAGE_TOL if k != "query_pos" else 2e-6)
+    check_against(g, "f64/query_pos", st["query_pos"], 2e-6)
+    check_against(g, "f64/sr", sr, 2e-5, 5e-5)
+    check_against(g, "sr", sr, 2e-5, 5e-5)
+    L = eng.L
+    per = torch.empty(B, device="cuda")
+    L.image_loss_fwd(sr, hr, per, B, 4, 32, 128, 1.0, 1e-4)
+    np.testing.assert_allclose(per.cpu().numpy(), g["image_loss"], rtol=2e-5)
+    dsr = torch.empty_like(sr)
+    L.image_loss_bwd(sr, hr, None, 100.0 / B, dsr, B, 4, 32, 128, 1.0, 1e-4)
+    G = {n: torch.zeros_like(q) for n, q in m.named_parameters()}
+    eng.backward(ctx, dsr, G)
+    from tatt_amd.engine import unused_param
+    check_grads(g, lambda n: None if unused_param(n) else G[n].cpu(), rtol64=1.5e-3, rtol32=1.5e-3, scale=stn_scale)
+    sd = m.state_dict()
+    for k in [k for k in g if k.startswith("bn:")]:
+        check_against(g, k, sd[k[3:]], 1e-5)
+
+
+def test_config4_rotated_small_batch_vs_reference_golden():
+    """BASELINE config 4 at B = 4 (full tensors in the fixture): rotated LR -> STN head -> control points -> TPS grid -> rectified
+    image -> SR output, train mode, against the real reference (model/stn_head.py:92-106, model/tps_spatial_transformer.py:97-112)."""
+    B, K = 4, 37
+    g = load_golden("tsrn_K37_B4_rot_train.npz")
+    m = build(K).train()
+    hr, lr, tp = [t.cuda() for t in procgen.make_inputs(B, K, seed=0)]
+    eng = m.engine()
+    arc = torch.from_numpy(g["arc"]).cuda()
+    d_lr = torch.empty_like(lr)
+    eng.L.rotate_fwd(lr, arc, d_lr, B, 4, 16, 64)
+    np.testing.assert_allclose(d_lr.cpu().numpy(), g["rot_lr"], atol=2e-5)   # bilinear weights from fp32 coordinates (same bound as the oracle pin)
+    sr, ctx = eng.forward(d_lr, tp, True, 0, p_drop=0.0)
+    ctrl = ctx["stn"][5].view(B, 20, 2)
+    np.testing.assert_allclose(ctrl.cpu().numpy(), g["f64/ctrl_points"], atol=2e-5)
+    # the rotation must actually move the control points away from the identity grid the STN bias encodes
+    ident = m.state_dict()["stn_head.stn_fc2.bias"].view(20, 2).cpu()
+    assert float((ctrl.cpu() - ident).abs().max()) > 1e-3
+    check_against(g, "f64/tps_out", nchw(ctx["xs"], B), 1e-4)
+    check_against(g, "tps_out", nchw(ctx["xs"], B), 1e-4)
+    check_against(g, "f64/sr", sr, 1e-4, 2e-4)
+
+
 @pytest.mark.parametrize("K,B", [(37, 2), (37, 5), (2448, 2)])
 def test_train_step_vs_reference_golden(K, B):
     g = load_golden(f"tsrn_K{K}_B{B}_train.npz")

@@ -29,13 +29,24 @@ def test_eval_forward(B):
         check_against(g, k, inter[k], TOL)
 
 
-@pytest.mark.parametrize("K,B", [(37, 2), (37, 5), (2448, 2)])
-def test_train_forward_backward_step(K, B):
-    g = load_golden(f"tsrn_K{K}_B{B}_train.npz")
+def stn_scale(n):
+    """B=64 gradient pins: the STN head (ReLU / max-pool decisions, x64 pixel scaling) gets 4x the tolerance of everything else."""
+    return 4.0 if n.startswith("stn_head.") else 1.0
+
+
+@pytest.mark.parametrize("K,B,rot", [(37, 2, False), (37, 5, False), (2448, 2, False), (37, 64, False), (37, 4, True), (37, 64, True)])
+def test_train_forward_backward_step(K, B, rot):
+    """rot = BASELINE config 4: LR / HR pre-deformed by the reference's rotation (model/__init__.py:4-30), +-10 degrees.
+    B = 64 = BASELINE config 2 at its own size (64-step RPE chain over the batch axis, well-conditioned BatchNorm)."""
+    g = load_golden(f"tsrn_K{K}_B{B}_{'rot_' if rot else ''}train.npz")
     P = leafify(make_state(K))
     hr, lr, tp = procgen.make_inputs(B, K, seed=0)
+    if rot:
+        arc = torch.from_numpy(g["arc"])
+        lr, hr = R.rotate(lr, arc), R.rotate(hr, arc)
+        check_against(g, "rot_lr", lr, 2e-6)
     inter = {}
-    sr = R.tsrn_forward(P, lr, tp, training=True, inter=inter)
+    sr = R.tsrn_forward(P, lr, tp, training=True, inter=inter, fused_rnn=B > 8)
     check_against(g, "sr", sr, TOL, 1e-4)     # train mode: tiny-batch BN statistics amplify rounding
     check_against(g, "ctrl_points", inter["ctrl_points"], TOL)
     # the STN's tiny-batch BatchNorm + the x64 pixel scaling of grid_sample amplify fp32 rounding of the control
@@ -47,7 +58,10 @@ def test_train_forward_backward_step(K, B):
     loss = per.mean() * 100
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=2e-5)
     loss.backward()
-    check_grads(g, lambda n: P[n].grad)
+    if B >= 64:       # well conditioned: 1.5e-3 of the reference's fp64 run (STN head 6e-3), measured <= 1.3e-3 / 4e-3
+        check_grads(g, lambda n: P[n].grad, rtol64=1.5e-3, rtol32=1.5e-3, scale=stn_scale)
+    else:
+        check_grads(g, lambda n: P[n].grad)
     names = [str(n) for n in g["grad_names"]]
     for k in [k for k in g if k.startswith("bn:")]:
         check_against(g, k, P[k[3:]], 1e-5)
@@ -73,6 +87,17 @@ def test_losses_and_metrics():
     np.testing.assert_allclose(R.tri_ssim(sr, sr2, hr).item(), g["tri_ssim"], rtol=1e-5)
     np.testing.assert_allclose(R.ssim(sr, hr).item(), g["ssim"], rtol=1e-5)
     np.testing.assert_allclose(R.psnr(sr, hr).item(), g["psnr"], rtol=1e-6)
+
+
+def test_semantic_loss_vs_reference_golden():
+    """oracle/crnn_ref.semantic_loss against loss/semantic_loss.py:21-38 run by tests/golden/make_golden.py (value + gradient)."""
+    from oracle import crnn_ref as C
+    g = load_golden("losses.npz")
+    pred = torch.from_numpy(g["sem_pred"]).requires_grad_(True)
+    loss = C.semantic_loss(pred, torch.from_numpy(g["sem_gt"]))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["sem_loss"], rtol=1e-6)
+    np.testing.assert_allclose(pred.grad.numpy(), g["sem_dpred"], rtol=1e-5, atol=1e-9)
 
 
 def test_fused_rnn_matches_loop():

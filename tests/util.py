@@ -71,8 +71,8 @@ GRAD_RTOL64 = 1.5e-3
 GRAD_RTOL32 = 1e-2
 
 
-def check_grads(gold, grad_of, rtol64=GRAD_RTOL64, rtol32=GRAD_RTOL32):
-    """gold: a *_train.npz fixture; grad_of(name) -> tensor or None."""
+def check_grads(gold, grad_of, rtol64=GRAD_RTOL64, rtol32=GRAD_RTOL32, scale=None):
+    """gold: a *_train.npz fixture; grad_of(name) -> tensor or None; scale(name) -> per-tensor multiplier of the tolerances."""
     names = [str(n) for n in gold["grad_names"]]
     total = float(gold["grad_total_norm"])
     for pre, rtol in (("f64/", rtol64), ("", rtol32)):
@@ -83,11 +83,12 @@ def check_grads(gold, grad_of, rtol64=GRAD_RTOL64, rtol32=GRAD_RTOL32):
                 continue
             assert got is not None, f"{n}: missing gradient"
             v = got.double().norm().item()
-            rt = 5 * rtol if got.numel() == 1 else rtol
+            rt = (5 * rtol if got.numel() == 1 else rtol) * (scale(n) if scale else 1.0)
             # atol: conv/linear biases in front of a BatchNorm have a mathematically zero gradient (rounding noise)
             assert abs(v - ref) <= rt * ref + 1e-6 * total, f"{pre}grad norm {n}: {v} vs {ref}"
         for k in [k for k in gold if k.startswith(pre + "grad:")]:
             name = k[len(pre) + 5:].split("@")[0]
             if k.endswith("@stats"):
                 continue
-            check_against(gold, pre + "grad:" + name, grad_of(name), 5 * rtol if grad_of(name).numel() == 1 else rtol)
+            check_against(gold, pre + "grad:" + name, grad_of(name),
+                          (5 * rtol if grad_of(name).numel() == 1 else rtol) * (scale(name) if scale else 1.0))
