@@ -151,6 +151,12 @@ int tatt_rotate_bwd(const float* arc, const float* dy, float* dx, int B, int C, 
  * dmean * d(mean)/d(x1), d(x2) (x3 = the HR image takes no gradient). */
 size_t tatt_ssim_workspace(int B, int C);
 int tatt_tri_ssim_fwd(const float* x1, const float* x2, const float* x3, float* out, int B, int C, int H, int W, float* workspace, hipStream_t stream);
+/* No counterpart in the reference: tatt_tri_ssim_fwd for callers that cannot allocate or pass a workspace -- code under hipGraph
+ * capture, tight evaluation / serving loops, harnesses that forbid hipMalloc.  Same result, bit for bit; the per-plane partial
+ * sums live in a 64 KB static device array of the library (one copy per GPU, held until the process ends), so B*C <= 16384 planes
+ * or the call is refused with an error.  It calls no hipMalloc / hipFree.  Calls that overlap in time on one GPU race on that
+ * array; the first call on each device resolves the array's address and must be made outside stream capture. */
+int tatt_tri_ssim_fwd_static(const float* x1, const float* x2, const float* x3, float* out, int B, int C, int H, int W, hipStream_t stream);
 int tatt_tri_ssim_bwd(const float* x1, const float* x2, const float* x3, float dmean, float* dx1, float* dx2, int accumulate, int B, int C, int H, int W, hipStream_t stream);
 int tatt_ssim_fwd(const float* x1, const float* x2, float* out, int B, int Ctot, int Cuse, int H, int W, float* workspace, hipStream_t stream);
 int tatt_psnr(const float* x1, const float* x2, float* out, int B, int Ctot, int Cuse, int H, int W, float* workspace, hipStream_t stream);

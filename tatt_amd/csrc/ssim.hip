@@ -5,6 +5,7 @@
 // F.conv2d(padding=5, groups=C)).  A plane is 32x128 = 16 KB, so the pass is a few hundred MFLOP of VALU work per step:
 // no tiling tricks are needed, the point is to keep the nine blurred maps out of HBM.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -198,6 +199,38 @@ __global__ __launch_bounds__(256) void tri_ssim_bwd_k(const float* __restrict__ 
   }
 }
 
+// ---- scratch of tatt_tri_ssim_fwd_static: the per-plane partial sums that tatt_tri_ssim_fwd takes from its `workspace`
+// argument, held in the code object instead so that the entry point allocates nothing.  64 KB per GPU the library runs on, for
+// the life of the process.  In host code `scratch` is only a stand-in for the symbol: the device address is resolved once per
+// device with hipGetSymbolAddress and kept in static_ptr[]; host code passes THAT to the kernels.
+constexpr int STATIC_MAX_PLANES = 16384;
+constexpr int STATIC_MAX_DEVICES = 64;
+static __device__ __align__(256) float scratch[STATIC_MAX_PLANES];
+float* static_ptr[STATIC_MAX_DEVICES] = {nullptr};
+std::mutex static_mu;
+
+// device address of this GPU's copy of `scratch` (each GPU holds its own copy at its own address)
+int static_scratch(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= STATIC_MAX_DEVICES) {
+    tatt_set_error("tatt_tri_ssim_fwd_static: no current device (%s)", hipGetErrorString(e));
+    return TATT_ERR_ARG;
+  }
+  std::lock_guard<std::mutex> lock(static_mu);
+  if (!static_ptr[dev]) {
+    float* p = nullptr;
+    e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+      tatt_set_error("tatt_tri_ssim_fwd_static: hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+      return TATT_ERR_LAUNCH;
+    }
+    static_ptr[dev] = p;
+  }
+  *out = static_ptr[dev];
+  return TATT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -214,6 +247,26 @@ int tatt_tri_ssim_fwd(const float* x1, const float* x2, const float* x3, float* 
   TATT_LAUNCH_CHECK("tri_ssim_fwd");
   hipLaunchKernelGGL(ssim_final_k, dim3(1), dim3(64), 0, st, workspace, B * C, 1.f / ((float)B * C * H * W), out, 0);
   TATT_LAUNCH_CHECK("tri_ssim_final");
+  return TATT_OK;
+}
+
+// tatt_tri_ssim_fwd without a workspace argument and without any allocation: the partial sums go to this GPU's copy of the
+// file-scope `scratch` array (at most STATIC_MAX_PLANES = 16384 planes, i.e. B*C <= 16384; larger calls are refused).  Every plane's
+// slot is overwritten before it is read, so nothing needs clearing between calls; two calls that overlap in time on one GPU
+// (different streams) race on the array -- serialise them.  The first call on a device resolves the array's address
+// (hipGetSymbolAddress) and must therefore be made outside stream capture; later calls only enqueue the two kernels.
+int tatt_tri_ssim_fwd_static(const float* x1, const float* x2, const float* x3, float* out, int B, int C, int H, int W, hipStream_t st) {
+  TATT_CHECK_ARG(x1 && x2 && x3 && out && B > 0 && C > 0 && H > 0 && W > 0 && H * W <= MAXHW,
+                 "tatt_tri_ssim_fwd_static: bad arguments (H*W must be <= %d)", MAXHW);
+  TATT_CHECK_ARG((long)B * C <= STATIC_MAX_PLANES, "tatt_tri_ssim_fwd_static: B*C = %ld planes exceed the static scratch (%d planes); "
+                 "use tatt_tri_ssim_fwd with a caller-provided workspace", (long)B * C, STATIC_MAX_PLANES);
+  float* ws = nullptr;
+  if (int rc = static_scratch(&ws)) return rc;
+  const Gauss G = make_gauss();
+  hipLaunchKernelGGL(tri_ssim_fwd_k, dim3(B * C), dim3(256), 0, st, x1, x2, x3, ws, H, W, G);
+  TATT_LAUNCH_CHECK("tri_ssim_fwd_static");
+  hipLaunchKernelGGL(ssim_final_k, dim3(1), dim3(64), 0, st, ws, B * C, 1.f / ((float)B * C * H * W), out, 0);
+  TATT_LAUNCH_CHECK("tri_ssim_final_static");
   return TATT_OK;
 }
 
