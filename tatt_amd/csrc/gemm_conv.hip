@@ -43,6 +43,11 @@ struct GemmArgs {
   int kchunk;     // K range per split (multiple of BK)
   int accumulate; // C += result
   int relu;
+  const float* A2;  // OP_STRIDED A, FAST only: k >= ksplit is read from A2 (k - ksplit), same row stride: A = [A | A2] without a concat
+  int ksplit;       // multiple of BK; INT_MAX = single source
+  float* C2;        // columns n >= nsplit are written to C2[m*ldc2 + n - nsplit] (accumulate2); nsplit multiple of BN, INT_MAX = none
+  int nsplit, accumulate2;
+  long ldc2;
   int bf16;       // host only: operands rounded to bf16 on their way into the matrix core (TATT_BF16 flag of the entry point)
   ConvGeom g;     // for OP_IM2COL / OP_CONVW / OP_IM2COL_N
   long w_sn, w_sci, w_stap, w_base;  // OP_CONVW: W[n*w_sn + ci*w_sci + w_base + tap*w_stap]
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   const int kq = tid & 7, r0 = tid >> 3;
   // A row-contiguous: m offset (tid&31)*4, k rows (tid>>5)+16j ; B row-contiguous: n offset (tid&15)*4, k row tid>>4
   const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(Ap), rsrcB = make_rsrc(Bp);
+  const __amdgpu_buffer_rsrc_t rsrcA2 = make_rsrc(a.A2 ? a.A2 : Ap);
   int a_py[2], a_px[2], a_off[2];  // OP_IM2COL: pixel (y, x) of the thread's rows and their byte offset (tap (0,0), ci 0)
   if constexpr (AOP == OP_IM2COL) {
 #pragma unroll
@@ -285,8 +291,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
       // ---- A ----
       if constexpr (AOP == OP_STRIDED) {
         const bool p = fa_k[0] < lim;
+        const bool second = k0u >= a.ksplit;  // wave-uniform: the tile comes from the second source ([A | A2] along k)
+        const __amdgpu_buffer_rsrc_t rs = second ? rsrcA2 : rsrcA;
+        const int so = (second ? k0u - a.ksplit : k0u) * 4;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ra[j] = bload4s(rsrcA, p ? fa_vo[j] : BUF_OOB, k0u * 4);
+        for (int j = 0; j < 2; ++j) ra[j] = bload4s(rs, p ? fa_vo[j] : BUF_OOB, so);
       } else if constexpr (AOP == OP_ROWCONTIG) {
         const int so = k0u * (int)a.sak * 4;
 #pragma unroll
@@ -574,14 +583,22 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
     int n = n0 + wn * 32 + li;
     if (n >= a.N) return;
     float bv = (plain && a.bias) ? a.bias[n] : 0.f;
+    long ldc = a.ldc;
+    int accum = a.accumulate;
+    if (n0 >= a.nsplit) {  // block-uniform: this column tile belongs to the second destination
+      Cp = a.C2;
+      n -= a.nsplit;
+      ldc = a.ldc2;
+      accum = a.accumulate2;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m >= a.M) continue;
       float v = acc[r] + bv;
-      float* dst = Cp + (long)m * a.ldc + n;
+      float* dst = Cp + (long)m * ldc + n;
       if (plain) {
-        if (a.accumulate) v += *dst;
+        if (accum) v += *dst;
         if (a.relu) v = fmaxf(v, 0.f);
       }
       *dst = v;
@@ -708,6 +725,10 @@ __global__ __launch_bounds__(256) void skinny_gather(const float* __restrict__ Z
 }
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+inline void init_args(GemmArgs& a) {
+  memset(&a, 0, sizeof(a));
+  a.ksplit = a.nsplit = 0x7fffffff;  // single A source, single destination
+}
 const long GIB2 = 1L << 31;
 
 // Can both operands use the FAST loaders (see gemm_kernel)?  Offsets are 32-bit byte offsets from the operand base.
@@ -790,7 +811,7 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
   TATT_CHECK_ARG(splitk >= 1 && (splitk == 1 || workspace), "tatt_gemm: split-K needs a workspace");
   TATT_CHECK_ARG(splitk == 1 || batch == 1 || bias == nullptr, "tatt_gemm: batched split-K takes no bias");
   GemmArgs a;
-  memset(&a, 0, sizeof(a));
+  init_args(a);
   a.A = A; a.B = B; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K;
   a.sam = sam; a.sak = sak; a.sbn = sbn; a.sbk = sbk; a.ldc = ldc;
@@ -821,6 +842,36 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
   return TATT_OK;
 }
 
+// tatt_gemm over a k-concatenated A and/or into two destinations (see include/tatt_hip.h): the GRU blocks of the SRBs read
+// cat(conv features, text-prior map) and hand gradients back to both, without materialising the concatenation.
+int tatt_gemm_cat(const float* A, const float* A2, int ksplit, const float* B, float* C, float* C2, int nsplit, const float* bias, int M,
+                  int N, int K, long sam, long sbn, long sbk, long ldc, long ldc2, int accumulate, int accumulate2, int flags,
+                  hipStream_t st) {
+  TATT_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "tatt_gemm_cat: bad arguments");
+  TATT_CHECK_ARG(!A2 || (ksplit > 0 && ksplit < K && ksplit % BK == 0 && al16(A2)), "tatt_gemm_cat: ksplit must be a multiple of %d inside (0, K), A2 16-byte aligned", BK);
+  TATT_CHECK_ARG(!C2 || (nsplit > 0 && nsplit < N && nsplit % BN == 0), "tatt_gemm_cat: nsplit must be a multiple of %d inside (0, N)", BN);
+  GemmArgs a;
+  init_args(a);
+  a.A = A; a.B = B; a.C = C; a.bias = bias;
+  a.M = M; a.N = N; a.K = K;
+  a.sam = sam; a.sak = 1; a.sbn = sbn; a.sbk = sbk; a.ldc = ldc;
+  a.splitk = 1;
+  a.accumulate = accumulate; a.relu = flags & TATT_RELU; a.bf16 = (flags & TATT_BF16) != 0;
+  a.kchunk = cdiv(K, BK) * BK;
+  if (A2) { a.A2 = A2; a.ksplit = ksplit; }
+  if (C2) { a.C2 = C2; a.nsplit = nsplit; a.ldc2 = ldc2; a.accumulate2 = accumulate2; }
+  const bool brow = (sbn == 1 && sbk != 1);
+  // the second source is read through the FAST loader only; its extent is checked like the first one's
+  const long ka = A2 ? ksplit : K, kb = A2 ? K - ksplit : 0;
+  TATT_CHECK_ARG(((long)M * sam + (ka > kb ? ka : kb)) * 4 < GIB2, "tatt_gemm_cat: A operands must stay below 2 GiB");
+  if (brow) {
+    TATT_CHECK_ARG((fast_ok<OP_STRIDED, OP_ROWCONTIG>(a)), "tatt_gemm_cat: operands must be 16-byte aligned with K, strides multiples of 4");
+    return launch<OP_STRIDED, OP_ROWCONTIG>(a, 1, st);
+  }
+  TATT_CHECK_ARG((fast_ok<OP_STRIDED, OP_STRIDED>(a)), "tatt_gemm_cat: operands must be 16-byte aligned with K, strides multiples of 4");
+  return launch<OP_STRIDED, OP_STRIDED>(a, 1, st);
+}
+
 // NHWC convolution, stride 1, zero padding (KH/2, KW/2):  Y[p, co] = bias[co] + sum_{tap,ci} X[p+tap, ci] * Wv(co, ci, tap)
 // Wv(co,ci,tap) = Wt[co*w_sn + ci*w_sci + w_base + tap*w_stap]:
 //   forward with OIHW weights [Cout,Cin,KH,KW]:  w_sn=Cin*T, w_sci=T, w_base=0,   w_stap=1
@@ -849,7 +900,7 @@ int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, flo
   TATT_CHECK_ARG((KH & 1) && (KW & 1), "tatt_conv_fwd: odd kernels only");
   TATT_CHECK_ARG((long)B * H * W * ldx * 4 < (1L << 31) && (long)Cout * Cin * KH * KW * 4 < (1L << 31), "tatt_conv_fwd: operands must stay below 2 GiB (32-bit buffer offsets)");
   GemmArgs a;
-  memset(&a, 0, sizeof(a));
+  init_args(a);
   a.A = X; a.B = Wt; a.C = Y; a.bias = bias;
   a.M = B * H * W; a.N = Cout; a.K = KH * KW * Cin;
   a.ldc = ldy;
@@ -895,7 +946,7 @@ int tatt_conv_skinny_fwd(const float* X, const float* Wt, const float* bias, flo
                      w_stap);
   TATT_LAUNCH_CHECK("skinny_repack_w");
   GemmArgs a;
-  memset(&a, 0, sizeof(a));
+  init_args(a);
   a.A = Wr; a.B = X; a.C = Z;
   a.M = T * Cout; a.N = (int)P; a.K = Cin;
   a.sam = Cin; a.sak = 1; a.sbn = ldx; a.sbk = 1; a.ldc = P;
@@ -924,7 +975,7 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
   TATT_CHECK_ARG(splitk >= 1 && workspace, "tatt_conv_wgrad: workspace required");
   TATT_CHECK_ARG((long)B * H * W * ldx * 4 < (1L << 31) && (long)B * H * W * lddy * 4 < (1L << 31), "tatt_conv_wgrad: operands must stay below 2 GiB (32-bit buffer offsets)");
   GemmArgs a;
-  memset(&a, 0, sizeof(a));
+  init_args(a);
   const int T = KH * KW;
   a.A = dY; a.B = X; a.C = workspace;
   a.M = Cout; a.N = T * Cin; a.K = B * H * W;

@@ -286,7 +286,7 @@ class Engine:
     def conv(self, x, W, b, out, B, H, Wd, Cin, Cout, k, acc=0, relu=0, fp32=False):
         T = k * k
         if Cout in (4, 8, 16) and not relu:
-            return self._skinny(x, W, b, out, B, H, Wd, Cin, Cout, k, (Cin * T, T, 0, 1), acc)
+            return self._skinny(x, W, b, out, B, H, Wd, Cin, Cout, k, (Cin * T, T, 0, 1), acc, fp32)
         self.L.conv_fwd_splitk(x, self._packed(W, Cout, Cin, k)[0], b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout,
                                T * Cin, 1, 0, Cin, acc, relu | (0 if fp32 else self.pf), self._conv_splitk(B * H * Wd, Cout, T * Cin),
                                self.ws)
@@ -346,74 +346,78 @@ class Engine:
             return (B * W, H, W, H * W, 1, W)
         return (B * H, W, 1, W, 0, 1)
 
-    def _gru_pack(self):
-        """W_ih / b_ih of the forward and reverse direction of every BiGRU block stacked as [n][192][64] / [n][192], gathered by
-        one launch per forward call (tatt_multi_copy): both directions' input projections (and their input gradient) are then
-        one GEMM with N (K) = 192 instead of two with 96."""
+    def _gru_fold(self):
+        """Per forward call, ONE launch (tatt_gru_fold_w) composes every GruBlock's 1x1 conv with the stacked forward / reverse GRU
+        input projection: Wf = W_ih W_c [192][Cin], bf = W_ih b_c + b_ih (model/tsrn.py:1083,:1088 have no non-linearity between
+        them).  Returns {block prefix: (Wf, bf)}; the [R,64] conv output and its GEMMs (forward, input gradient, weight gradient)
+        never exist."""
         pk = self.wpack.get("gru")
         if pk is None:
+            P = self.P
             pres = [f"block{i + 2}.gru{j}." for i in range(self.m.srb_nums) for j in (1, 2)]
             n = len(pres)
-            Wp, bp = self.new(n, 192, 64), self.new(n, 192)
-            src, off, ln = [], [], []
-            for i, pre in enumerate(pres):
-                for d, sfx in enumerate(["", "_reverse"]):
-                    src += [self.P[pre + "gru.weight_ih_l0" + sfx], self.P[pre + "gru.bias_ih_l0" + sfx]]
-                    off += [(i * 192 + d * 96) * 64, n * 192 * 64 + i * 192 + d * 96]
-                    ln += [96 * 64, 96]
-            buf = self.new(n * 192 * 64 + n * 192)
-            k = len(src)
-            for c0 in range(0, k, 64):
-                c1 = min(k, c0 + 64)
-                m = c1 - c0
-                self.L.multi_copy(m, (ctypes.c_void_p * m)(*[t.data_ptr() for t in src[c0:c1]]), (ctypes.c_long * m)(*off[c0:c1]),
-                                  (ctypes.c_long * m)(*ln[c0:c1]), buf)
-            Wp, bp = buf[:n * 192 * 64].view(n, 192, 64), buf[n * 192 * 64:].view(n, 192)
-            pk = self.wpack["gru"] = (Wp, bp, {pre: i for i, pre in enumerate(pres)})
+            cin = [P[pre + "conv1.weight"].shape[1] for pre in pres]
+            buf = self.new(sum(192 * c + 192 for c in cin))
+            pk, o = {}, 0
+            for pre, c in zip(pres, cin):
+                pk[pre] = (buf[o:o + 192 * c].view(192, c), buf[o + 192 * c:o + 192 * c + 192])
+                o += 192 * c + 192
+            VP = ctypes.c_void_p
+            ptr = lambda ts: [t.data_ptr() for t in ts]
+            self.L.gru_fold_w(n, (VP * n)(*ptr([P[pre + "conv1.weight"] for pre in pres])), (VP * n)(*ptr([P[pre + "conv1.bias"] for pre in pres])),
+                              (VP * (2 * n))(*ptr([P[pre + "gru.weight_ih_l0" + sfx] for pre in pres for sfx in ("", "_reverse")])),
+                              (VP * (2 * n))(*ptr([P[pre + "gru.bias_ih_l0" + sfx] for pre in pres for sfx in ("", "_reverse")])),
+                              (VP * n)(*ptr([pk[pre][0] for pre in pres])), (VP * n)(*ptr([pk[pre][1] for pre in pres])),
+                              (ctypes.c_int * n)(*cin))
+            self.wpack["gru"] = pk
         return pk
 
     def gru_block_fwd(self, pre, inputs, B, H, W, vertical, save, ctx, key):
-        """inputs: list of (x[R,Kc], column offset in conv1.weight, Kc).  Returns out [R,64]."""
+        """inputs: one or two [R,64] tensors whose channel concatenation is the block's input.  Returns out [R,64]."""
         P, R = self.P, B * H * W
-        Wc = P[pre + "conv1.weight"]
-        Ktot = Wc.shape[1]
-        g_in = self.new(R, 64)
-        for i, (x, off, kc) in enumerate(inputs):
-            self.linear(x, Wc.view(-1)[off:], P[pre + "conv1.bias"] if i == 0 else None, g_in, R, 64, kc, ldw=Ktot, acc=int(i > 0))
+        Wf, bf = self._gru_fold()[pre]
+        Cin = Wf.shape[1]
+        assert Cin == 64 * len(inputs)
         gi = self.new(R, 192)
-        Wp, bp, ix = self._gru_pack()
-        self.linear(g_in, Wp[ix[pre]], bp[ix[pre]], gi, R, 192, 64)
+        self.L.gemm_cat(inputs[0], inputs[1] if len(inputs) > 1 else None, 64, Wf, gi, None, 0, bf, R, 192, Cin, 64, Cin, 1, 192, 0,
+                        0, 0, self.pf)
         out = self.new(R, 64)
         sv = self.new(R, 2, 4, 32) if save else None
         self.L.gru32_fwd(gi, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], P[pre + "gru.bias_hh_l0"],
                          P[pre + "gru.bias_hh_l0_reverse"], out, sv, *self._seqmap(B, H, W, vertical))
         if save:
-            ctx[key] = (g_in, out, sv)
+            ctx[key] = (out, sv)
         return out
 
     def gru_block_bwd(self, pre, dout, inputs, B, H, W, vertical, ctx, key, G):
-        """inputs: list of (x, off, kc, dx or None, acc).  Writes parameter grads, input grads into dx."""
-        P, R = self.P, B * H * W
-        g_in, out, sv = ctx[key]
+        """inputs: list of (x [R,64], dx [R,64], acc) per concatenated input.  Writes parameter grads, input grads into dx."""
+        P, R, L = self.P, B * H * W, self.L
+        out, sv = ctx[key]
         dgi, dgh, hprev = self.new(R, 192), self.new(R, 192), self.new(R, 64)
-        self.L.gru32_bwd(dout, out, sv, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], dgi, dgh, hprev,
-                         *self._seqmap(B, H, W, vertical))
-        dg_in = self.new(R, 64)
-        wg = []                                               # all weight gradients of the block: one grouped launch
+        L.gru32_bwd(dout, out, sv, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], dgi, dgh, hprev,
+                    *self._seqmap(B, H, W, vertical))
+        Wf, _ = self._gru_fold()[pre]
+        Cin = Wf.shape[1]
+        tmp = self.zeros(192 * Cin + 192)                     # gradient of the composed (Wf, bf); unfolded onto W_ih, W_c, biases below
+        dWf, dbf = tmp[:192 * Cin], tmp[192 * Cin:]
+        wg = []                                               # all streaming weight gradients of the block: one grouped launch
         for d, sfx in enumerate(["", "_reverse"]):
             gi_d, gh_d, hp_d = dgi.view(-1)[96 * d:], dgh.view(-1)[96 * d:], hprev.view(-1)[32 * d:]
             wg.append((gh_d, hp_d, G[pre + "gru.weight_hh_l0" + sfx], G[pre + "gru.bias_hh_l0" + sfx], R, 96, 32, 192, 64, None))
-            wg.append((gi_d, g_in, G[pre + "gru.weight_ih_l0" + sfx], G[pre + "gru.bias_ih_l0" + sfx], R, 96, 64, 192, None, None))
-        Wp, _, ix = self._gru_pack()
-        self.linear_dx(dgi, Wp[ix[pre]], dg_in, R, 192, 64)
-        Wc, dWc = P[pre + "conv1.weight"], G[pre + "conv1.weight"]
-        Ktot = Wc.shape[1]
-        for i, (x, off, kc, dx, acc) in enumerate(inputs):
-            wg.append((dg_in, x, dWc.view(-1)[off:], G[pre + "conv1.bias"] if i == 0 else None, R, 64, kc, None, None, Ktot))
+            for s, (x, _, _) in enumerate(inputs):
+                wg.append((gi_d, x, dWf[96 * d * Cin + 64 * s:], dbf[96 * d:] if s == 0 else None, R, 96, 64, 192, None, Cin))
         self.linear_dwb_group(wg)                             # queued before the input gradients below may update a dx in place
-        for i, (x, off, kc, dx, acc) in enumerate(inputs):
-            if dx is not None:
-                self.linear_dx(dg_in, Wc.view(-1)[off:], dx, R, 64, kc, ldw=Ktot, acc=acc)
+        sfxs = ("", "_reverse")
+        self._wgrad(lambda ws: L.gru_unfold_grad(dWf, dbf, P[pre + "conv1.weight"], P[pre + "conv1.bias"],
+                                                 *[P[pre + "gru.weight_ih_l0" + x] for x in sfxs],
+                                                 *[G[pre + "gru.weight_ih_l0" + x] for x in sfxs],
+                                                 *[G[pre + "gru.bias_ih_l0" + x] for x in sfxs],
+                                                 G[pre + "conv1.weight"], G[pre + "conv1.bias"], Cin), [tmp])
+        for _, dx, _ in inputs:
+            self._guard(dx)
+        two = len(inputs) > 1
+        L.gemm_cat(dgi, None, 0, Wf, inputs[0][1], inputs[1][1] if two else None, 64, None, R, Cin, 192, 192, 1, Cin, 64, 64,
+                   inputs[0][2], inputs[1][2] if two else 0, self.pf)
 
     # ---- attention block pieces ------------------------------------------------------------------------------------
     def mha_fwd(self, pre, q_in, k_in, v_in, B, Lq, cfg):
@@ -517,7 +521,7 @@ class Engine:
         use_stn = bool(m.stn and training)
         ctx["x"] = x
         self._prepack(use_stn)
-        self._gru_pack()
+        self._gru_fold()
 
         # ---- recurrent positional encoding (model/transformer_v2.py:215-221): GRU over the batch axis, identical input at
         # every step.  It depends on weights only and is a chain of B dependent, latency-bound launches, so it is forked
@@ -667,10 +671,10 @@ class Engine:
         for i in range(m.srb_nums):
             pre = f"block{i + 2}."
             ca, ma, st1, cb, r2, st2 = first_convs if i == 0 else srb_convs(pre, blk)
-            r = self.gru_block_fwd(pre + "gru1.", [(r2, 0, 64), (tp_map, 64, 64)], B, H, W, True, want_ctx, ctx, pre + "gru1")
+            r = self.gru_block_fwd(pre + "gru1.", [r2, tp_map], B, H, W, True, want_ctx, ctx, pre + "gru1")
             s = self.new(R0, 64)
             L.axpby(blk, 1.0, r, 1.0, s, R0 * 64, 0)
-            out = self.gru_block_fwd(pre + "gru2.", [(s, 0, 64)], B, H, W, False, want_ctx, ctx, pre + "gru2")
+            out = self.gru_block_fwd(pre + "gru2.", [s], B, H, W, False, want_ctx, ctx, pre + "gru2")
             srbs.append((blk, ca, st1, ma, cb, st2, r2, s))
             blk = out
         ctx["srbs"] = srbs
@@ -686,7 +690,8 @@ class Engine:
         up = self.new(4 * R0, 64)
         L.pixshuf_mish_fwd(cu, up, B, H, W, 64)
         pre_s = self.new(4 * R0, 4)
-        self.conv(up, P[k8 + "1.weight"], P[k8 + "1.bias"], pre_s, B, 2 * H, 2 * W, 64, 4, 9)
+        # the output convolution feeds the sigmoid directly (no normalisation behind it to absorb operand rounding): fp32 in both modes
+        self.conv(up, P[k8 + "1.weight"], P[k8 + "1.bias"], pre_s, B, 2 * H, 2 * W, 64, 4, 9, fp32=True)
         sr = self.new(B, 4, 2 * H, 2 * W)
         L.sigmoid_to_nchw(pre_s, sr, B, 4, 4 * H * W)
         ctx["tail"] = (blk, c7, st7, u_in, cu, up, pre_s)
@@ -732,9 +737,9 @@ class Engine:
         # ---- tail ------------------------------------------------------------------------------------------------
         dpre = self.new(4 * R0, 4)
         L.sigmoid_bwd_to_nhwc(ctx["sr"], dsr, dpre, B, 4, 4 * H * W)
-        self.conv_wgrad(up, dpre, G[k8 + "1.weight"], G[k8 + "1.bias"], B, 2 * H, 2 * W, 64, 4, 9)
+        self.conv_wgrad(up, dpre, G[k8 + "1.weight"], G[k8 + "1.bias"], B, 2 * H, 2 * W, 64, 4, 9, fp32=True)
         dup = self.new(4 * R0, 64)
-        self.conv_dgrad(dpre, P[k8 + "1.weight"], dup, B, 2 * H, 2 * W, 64, 4, 9)
+        self.conv_dgrad(dpre, P[k8 + "1.weight"], dup, B, 2 * H, 2 * W, 64, 4, 9, fp32=True)
         dcu = self.new(R0, 256)
         L.pixshuf_mish_bwd(cu, dup, dcu, B, H, W, 64)
         self.conv_wgrad(u_in, dcu, G[k8 + "0.conv.weight"], G[k8 + "0.conv.bias"], B, H, W, 64, 256, 3)
@@ -753,9 +758,9 @@ class Engine:
             pre = f"block{i + 2}."
             blk, ca, st1, ma, cb, st2, r2, s = ctx["srbs"][i]
             ds = self.new(R0, 64)
-            self.gru_block_bwd(pre + "gru2.", dout, [(s, 0, 64, ds, 0)], B, H, W, False, ctx, pre + "gru2", G)
+            self.gru_block_bwd(pre + "gru2.", dout, [(s, ds, 0)], B, H, W, False, ctx, pre + "gru2", G)
             dr2 = self.new(R0, 64)
-            self.gru_block_bwd(pre + "gru1.", ds, [(r2, 0, 64, dr2, 0), (tp_map, 64, 64, dtp, 0 if first_tp else 1)], B, H, W,
+            self.gru_block_bwd(pre + "gru1.", ds, [(r2, dr2, 0), (tp_map, dtp, 0 if first_tp else 1)], B, H, W,
                                True, ctx, pre + "gru1", G)
             first_tp = False
             self._w_flush()

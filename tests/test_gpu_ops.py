@@ -542,3 +542,54 @@ def test_tri_ssim_ssim_psnr(B, C, H, W):
         assert abs(out.item() - R.ssim(x1.double(), x3.double()).item()) < 2e-6
         L().psnr(cu(x1), cu(x3), out, B, C, 3, H, W, w)
         assert abs(out.item() - R.psnr(x1.double(), x3.double()).item()) < 1e-4
+
+
+# ---- GruBlock with the 1x1 conv folded into the GRU input projection -------------------------------------------------------------
+@pytest.mark.parametrize("M", [1000, 4096 + 17])
+def test_gemm_cat_two_sources_and_two_destinations(M):
+    """tatt_gemm_cat: C = [A1 | A2] B^T + bias (forward of a GruBlock on cat(features, text map)) and the split input gradient
+    (C, C2) (+)= dY W[:, :64], dY W[:, 64:] in one launch each, against fp64 matmuls."""
+    A1, A2, W, b = rnd(M, 64), rnd(M, 64, seed=1), rnd(192, 128, seed=2) * 0.1, rnd(192, seed=3)
+    gi = torch.empty(M, 192, device="cuda")
+    L().gemm_cat(cu(A1), cu(A2), 64, cu(W), gi, None, 0, cu(b), M, 192, 128, 64, 128, 1, 192, 0, 0, 0, 0)
+    ref = torch.cat([A1, A2], 1).double() @ W.double().t() + b.double()
+    close(gi, ref, what="cat forward")
+    gi1 = torch.empty(M, 192, device="cuda")                                  # single source: plain NT GEMM through the same entry
+    L().gemm_cat(cu(A1), None, 0, cu(W[:, :64]), gi1, None, 0, cu(b), M, 192, 64, 64, 64, 1, 192, 0, 0, 0, 0)
+    close(gi1, A1.double() @ W[:, :64].double().t() + b.double(), what="single source")
+    dY, d1, d2_0 = rnd(M, 192, seed=4), torch.empty(M, 64, device="cuda"), rnd(M, 64, seed=5)
+    d2 = cu(d2_0)
+    L().gemm_cat(cu(dY), None, 0, cu(W), d1, d2, 64, None, M, 128, 192, 192, 1, 128, 64, 64, 0, 1, 0)
+    dref = dY.double() @ W.double()
+    close(d1, dref[:, :64], what="dx first half")
+    close(d2, d2_0.double() + dref[:, 64:], what="dx second half (accumulated)")
+    with pytest.raises(RuntimeError, match="ksplit"):
+        L().gemm_cat(cu(A1), cu(A2), 48, cu(W), gi, None, 0, None, M, 192, 128, 64, 128, 1, 192, 0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("Cin", [64, 128])
+def test_gru_fold_and_unfold_vs_autograd(Cin):
+    """tatt_gru_fold_w / tatt_gru_unfold_grad against autograd of Wf = cat(W_ih_f, W_ih_r) W_c, bf = cat(W_ih) b_c + cat(b_ih) in fp64."""
+    import ctypes
+    Wc, bc = rnd(64, Cin, seed=1) * 0.2, rnd(64, seed=2) * 0.1
+    Wih = [rnd(96, 64, seed=3 + d) * 0.2 for d in range(2)]
+    bih = [rnd(96, seed=5 + d) * 0.1 for d in range(2)]
+    dWf, dbf = rnd(192, Cin, seed=7), rnd(192, seed=8)
+    leaves = [t.double().requires_grad_(True) for t in (Wc, bc, *Wih, *bih)]
+    wc, b_c, wf, wr, bfw, brv = leaves
+    Wst = torch.cat([wf, wr], 0)
+    Wf_ref, bf_ref = Wst @ wc, Wst @ b_c + torch.cat([bfw, brv])
+    ((Wf_ref * dWf.double()).sum() + (bf_ref * dbf.double()).sum()).backward()
+    VP = ctypes.c_void_p
+    d = {k: cu(v) for k, v in dict(Wc=Wc, bc=bc, wf=Wih[0], wr=Wih[1], bf_=bih[0], br=bih[1], dWf=dWf, dbf=dbf).items()}
+    Wf, bf = torch.empty(192, Cin, device="cuda"), torch.empty(192, device="cuda")
+    p = lambda *ts: [t.data_ptr() for t in ts]
+    L().gru_fold_w(1, (VP * 1)(*p(d["Wc"])), (VP * 1)(*p(d["bc"])), (VP * 2)(*p(d["wf"], d["wr"])), (VP * 2)(*p(d["bf_"], d["br"])),
+                   (VP * 1)(*p(Wf)), (VP * 1)(*p(bf)), (ctypes.c_int * 1)(Cin))
+    close(Wf, Wf_ref, 2e-6, "Wf")
+    close(bf, bf_ref, 2e-6, "bf")
+    g0 = [rnd(*t.shape, seed=20 + i) for i, t in enumerate((Wih[0], Wih[1], bih[0], bih[1], Wc, bc))]       # += onto existing gradients
+    g = [cu(t) for t in g0]
+    L().gru_unfold_grad(d["dWf"], d["dbf"], d["Wc"], d["bc"], d["wf"], d["wr"], g[0], g[1], g[2], g[3], g[4], g[5], Cin)
+    for got, base, leaf, nm in zip(g, g0, (wf, wr, bfw, brv, wc, b_c), ("dW_ih_f", "dW_ih_r", "db_ih_f", "db_ih_r", "dW_c", "db_c")):
+        close(got, base.double() + leaf.grad, 2e-6, nm)
