@@ -102,6 +102,19 @@ int tatt_bn_stat_from_running(const float* rm, const float* rv, int C, float eps
 int tatt_bn_apply(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr, float* y, long ldy, int R, int C, int act, hipStream_t stream);
 int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const float* stat, const float* gamma, const float* beta, float* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int act, int train, int accumulate_params, int accumulate_dx, float* workspace, hipStream_t stream);
 
+/* BatchNorm fused into the producing GEMM / convolution (model/tsrn.py:868-877 conv-BN pairs and their autograd): the first half of
+ * each BatchNorm pass -- the row reduction -- runs in the epilogue of the launch that produces the tensor, per 128-row block:
+ *   tatt_conv_fwd_bn(epi = 1): Y = conv(X) and partial[blk][2][Cout] = (mean, M2) of Y's rows -> tatt_bn_stats_from_partial
+ *       (rows_per_blk = 128) = the statistics half of tatt_bn_stats;
+ *   tatt_conv_fwd_bn(epi = 2) / tatt_gemm_cat_bnbwd: the launch computes dy, the gradient wrt y = act(BatchNorm(bn_x)); it stores
+ *       g = dy * act'(bn(bn_x)) instead and partial = (sum g, sum g xhat) -> tatt_bn_bwd_from_partial = the rest of tatt_bn_bwd.
+ * partial: cdiv(rows, 128) * 2 * C floats; weights packed (tatt_conv_pack_w); operand layouts as the FAST loaders need them
+ * (16-byte granular), else the call is refused.  tatt_gemm_cat_bnbwd: the BatchNorm (bn_C channels) sits on the first destination. */
+int tatt_conv_fwd_bn(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int flags, int epi, const float* bn_x, long bn_ldx, const float* bn_stat, const float* bn_gamma, const float* bn_beta, int bn_act, float* partial, hipStream_t stream);
+int tatt_gemm_cat_bnbwd(const float* A, const float* A2, int ksplit, const float* B, float* C, float* C2, int nsplit, const float* bias, int M, int N, int K, long sam, long sbn, long sbk, long ldc, long ldc2, int accumulate, int accumulate2, int flags, const float* bn_x, long bn_ldx, const float* bn_stat, const float* bn_gamma, const float* bn_beta, int bn_act, int bn_C, float* partial, hipStream_t stream);
+int tatt_bn_stats_from_partial(const float* partial, int nblk, int rows_per_blk, int R, int C, float eps, float momentum, float* stat, float* run_mean, float* run_var, hipStream_t stream);
+int tatt_bn_bwd_from_partial(const float* x, long ldx, const float* g, long ldg, const float* stat, const float* gamma, const float* beta, const float* partial, int nblk, float* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int train, int accumulate_params, int accumulate_dx, float* sums, hipStream_t stream);
+
 /* ---- LayerNorm(64) with fused residual + dropout (model/transformer_v2.py:478-482, :827-831, :380) -------- */
 int tatt_ln_fwd(const float* x, const float* res, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, const float* gamma, const float* beta, float* vout, float* y, int rows, float eps, hipStream_t stream);
 size_t tatt_ln_workspace(int rows);

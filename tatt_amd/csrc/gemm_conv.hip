@@ -48,6 +48,14 @@ struct GemmArgs {
   float* C2;        // columns n >= nsplit are written to C2[m*ldc2 + n - nsplit] (accumulate2); nsplit multiple of BN, INT_MAX = none
   int nsplit, accumulate2;
   long ldc2;
+  // EPI kernels (BatchNorm fused into the epilogue): per-row-block column statistics of the output tile go to epi_partial
+  // [gridDim.x][2][epi_C]; EPI 1 = (mean, M2) of C itself (forward batch statistics), EPI 2 = (sum g, sum g*xhat) with
+  // g = C * act'(bn(x)) and g stored in place of C (backward reduction of the BatchNorm whose output gradient this launch produces)
+  float* epi_partial;
+  const float* epi_x;  // EPI 2: the BatchNorm's input [M][epi_ldx]
+  long epi_ldx;
+  const float *epi_stat, *epi_gamma, *epi_beta;  // EPI 2: stat [2][epi_C] (mean, invstd)
+  int epi_act, epi_C;
   int bf16;       // host only: operands rounded to bf16 on their way into the matrix core (TATT_BF16 flag of the entry point)
   ConvGeom g;     // for OP_IM2COL / OP_CONVW / OP_IM2COL_N
   long w_sn, w_sci, w_stap, w_base;  // OP_CONVW: W[n*w_sn + ci*w_sci + w_base + tap*w_stap]
@@ -148,7 +156,13 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 // offsets (or the out-of-range offset where the tap falls off the image) once, in registers, and every later load is a
 // buffer_load with a register voffset and an immediate offset - no per-tile bounds tests, selects or scalar tile
 // bookkeeping, which otherwise cost MFMA issue slots 18 times per launch.
-template <int AOP, int BOP, bool FAST, bool BF16 = false, bool TAP9 = false>
+__device__ __forceinline__ float epi_act_grad(float t, int act) {
+  if (act == 1) return t > 0.f ? 1.f : 0.f;
+  if (act == 2) return mish_gradf_(t);
+  return 1.f;
+}
+
+template <int AOP, int BOP, bool FAST, bool BF16 = false, bool TAP9 = false, int EPI = 0>
 __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   static_assert(FAST || !BF16, "the bf16 path exists for the FAST loaders only");
   static_assert(!TAP9 || (FAST && AOP == OP_IM2COL && BOP == OP_CONVW_P), "TAP9 is the 3x3 Cin=64 im2col specialisation");
@@ -579,7 +593,95 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ------------------
   float* Cp = a.C + zb * a.sCb + zs * a.sCz;
   const bool plain = a.splitk == 1;
-  {
+  if constexpr (EPI != 0) {
+    // BatchNorm fused into the epilogue (host guarantees splitk == 1, no accumulate / relu on the first destination).  The
+    // workgroup's 128 x 64 tile is reduced over its rows: registers -> the two lane halves -> the four waves along M through LDS.
+    __syncthreads();  // every wave has finished reading the operand tiles: the LDS is free
+    float* red = lds;  // [2][4][64]
+    const int nl = wn * 32 + li, n = n0 + nl;
+    const bool first = n0 < a.nsplit;  // block-uniform: the BatchNorm sits on the first destination
+    const bool nok = n < a.N;
+    const bool sok = nok && first && n < a.epi_C;
+    const float bv = (a.bias && nok) ? a.bias[n] : 0.f;
+    float v[16];
+    bool ok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      ok[r] = m < a.M;
+      v[r] = acc[r] + bv;
+    }
+    const int cnt = min(BM, a.M - m0);
+    if constexpr (EPI == 1) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += ok[r] ? v[r] : 0.f;
+      s += __shfl_xor(s, 32, 64);
+      if (lh == 0) red[wm * 64 + nl] = s;
+      __syncthreads();
+      const float mean = (red[nl] + red[64 + nl] + red[128 + nl] + red[192 + nl]) / (float)cnt;
+      float q = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = v[r] - mean;
+        q += ok[r] ? d * d : 0.f;
+      }
+      q += __shfl_xor(q, 32, 64);
+      if (lh == 0) red[256 + wm * 64 + nl] = q;
+      __syncthreads();
+      if (wm == 0 && lh == 0 && sok) {
+        a.epi_partial[((long)bx * 2 + 0) * a.epi_C + n] = mean;
+        a.epi_partial[((long)bx * 2 + 1) * a.epi_C + n] = red[256 + nl] + red[256 + 64 + nl] + red[256 + 128 + nl] + red[256 + 192 + nl];
+      }
+    } else {
+      float s1 = 0.f, s2 = 0.f;
+      if (sok) {
+        float xv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          xv[r] = ok[r] ? a.epi_x[(long)m * a.epi_ldx + n] : 0.f;
+        }
+        const float mean = a.epi_stat[n], inv = a.epi_stat[a.epi_C + n], ga = a.epi_gamma[n], be = a.epi_beta[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float xh = (xv[r] - mean) * inv;
+          const float g = ok[r] ? v[r] * epi_act_grad(xh * ga + be, a.epi_act) : 0.f;
+          s1 += g;
+          s2 += g * xh;
+          v[r] = g;
+        }
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lh == 0) {
+        red[wm * 64 + nl] = s1;
+        red[256 + wm * 64 + nl] = s2;
+      }
+      __syncthreads();
+      if (wm == 0 && lh == 0 && sok) {
+        a.epi_partial[((long)bx * 2 + 0) * a.epi_C + n] = red[nl] + red[64 + nl] + red[128 + nl] + red[192 + nl];
+        a.epi_partial[((long)bx * 2 + 1) * a.epi_C + n] = red[256 + nl] + red[256 + 64 + nl] + red[256 + 128 + nl] + red[256 + 192 + nl];
+      }
+    }
+    if (!nok) return;
+    long ldc = a.ldc;
+    int accum = a.accumulate, nn = n;
+    if (!first) {
+      Cp = a.C2;
+      nn = n - a.nsplit;
+      ldc = a.ldc2;
+      accum = a.accumulate2;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (!ok[r]) continue;
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float* dst = Cp + (long)m * ldc + nn;
+      *dst = accum ? v[r] + *dst : v[r];
+    }
+    return;
+  } else {
     int n = n0 + wn * 32 + li;
     if (n >= a.N) return;
     float bv = (plain && a.bias) ? a.bias[n] : 0.f;
@@ -768,6 +870,28 @@ int launch(const GemmArgs& a, int batch, hipStream_t st) {
   return TATT_OK;
 }
 
+// launches with a BatchNorm epilogue (EPI 1 / 2, see GemmArgs): FAST loaders only, one K pass, whole tile rows
+template <int AOP, int BOP, int EPI>
+int launch_epi(const GemmArgs& a, hipStream_t st) {
+  if (!fast_ok<AOP, BOP>(a) || a.splitk != 1 || a.relu || a.accumulate || !a.epi_partial || a.epi_C <= 0) {
+    tatt_set_error("BatchNorm-epilogue launch: needs FAST operand layouts (16-byte granular), one K pass, no relu / accumulate");
+    return TATT_ERR_ARG;
+  }
+  dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), 1);
+  if constexpr (AOP == OP_IM2COL && BOP == OP_CONVW_P) {
+    if (g_tap9 && a.g.Cin == 64 && a.g.KH == 3 && a.g.KW == 3 && a.K == 576 && a.w_stap == 64) {
+      if (a.bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, true, EPI>), grid, dim3(NTHR), 0, st, a);
+      else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, false, true, EPI>), grid, dim3(NTHR), 0, st, a);
+      TATT_LAUNCH_CHECK("gemm_kernel<tap9, bn epilogue>");
+      return TATT_OK;
+    }
+  }
+  if (a.bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, false, EPI>), grid, dim3(NTHR), 0, st, a);
+  else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, false, false, EPI>), grid, dim3(NTHR), 0, st, a);
+  TATT_LAUNCH_CHECK("gemm_kernel<bn epilogue>");
+  return TATT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -844,9 +968,24 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
 
 // tatt_gemm over a k-concatenated A and/or into two destinations (see include/tatt_hip.h): the GRU blocks of the SRBs read
 // cat(conv features, text-prior map) and hand gradients back to both, without materialising the concatenation.
+int tatt_gemm_cat_bnbwd(const float* A, const float* A2, int ksplit, const float* B, float* C, float* C2, int nsplit, const float* bias,
+                        int M, int N, int K, long sam, long sbn, long sbk, long ldc, long ldc2, int accumulate, int accumulate2, int flags,
+                        const float* bn_x, long bn_ldx, const float* bn_stat, const float* bn_gamma, const float* bn_beta, int bn_act,
+                        int bn_C, float* partial, hipStream_t st);
+
 int tatt_gemm_cat(const float* A, const float* A2, int ksplit, const float* B, float* C, float* C2, int nsplit, const float* bias, int M,
                   int N, int K, long sam, long sbn, long sbk, long ldc, long ldc2, int accumulate, int accumulate2, int flags,
                   hipStream_t st) {
+  return tatt_gemm_cat_bnbwd(A, A2, ksplit, B, C, C2, nsplit, bias, M, N, K, sam, sbn, sbk, ldc, ldc2, accumulate, accumulate2, flags,
+                             nullptr, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, st);
+}
+
+// tatt_gemm_cat whose first destination is the output gradient of a BatchNorm (bn_x = that BatchNorm's input, partial != NULL):
+// the epilogue stores g = C * act'(bn(x)) and the per-row-block sums (sum g, sum g xhat) for tatt_bn_bwd_from_partial.
+int tatt_gemm_cat_bnbwd(const float* A, const float* A2, int ksplit, const float* B, float* C, float* C2, int nsplit, const float* bias,
+                        int M, int N, int K, long sam, long sbn, long sbk, long ldc, long ldc2, int accumulate, int accumulate2, int flags,
+                        const float* bn_x, long bn_ldx, const float* bn_stat, const float* bn_gamma, const float* bn_beta, int bn_act,
+                        int bn_C, float* partial, hipStream_t st) {
   TATT_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "tatt_gemm_cat: bad arguments");
   TATT_CHECK_ARG(!A2 || (ksplit > 0 && ksplit < K && ksplit % BK == 0 && al16(A2)), "tatt_gemm_cat: ksplit must be a multiple of %d inside (0, K), A2 16-byte aligned", BK);
   TATT_CHECK_ARG(!C2 || (nsplit > 0 && nsplit < N && nsplit % BN == 0), "tatt_gemm_cat: nsplit must be a multiple of %d inside (0, N)", BN);
@@ -864,6 +1003,13 @@ int tatt_gemm_cat(const float* A, const float* A2, int ksplit, const float* B, f
   // the second source is read through the FAST loader only; its extent is checked like the first one's
   const long ka = A2 ? ksplit : K, kb = A2 ? K - ksplit : 0;
   TATT_CHECK_ARG(((long)M * sam + (ka > kb ? ka : kb)) * 4 < GIB2, "tatt_gemm_cat: A operands must stay below 2 GiB");
+  if (partial) {
+    TATT_CHECK_ARG(brow && bn_x && bn_stat && bn_gamma && bn_beta && bn_C > 0 && bn_C <= (C2 ? nsplit : N),
+                   "tatt_gemm_cat_bnbwd: BatchNorm epilogue needs a row-contiguous B (input-gradient GEMM) and the BatchNorm's x / stat / gamma / beta");
+    a.epi_partial = partial; a.epi_x = bn_x; a.epi_ldx = bn_ldx; a.epi_stat = bn_stat; a.epi_gamma = bn_gamma; a.epi_beta = bn_beta;
+    a.epi_act = bn_act; a.epi_C = bn_C;
+    return launch_epi<OP_STRIDED, OP_ROWCONTIG, 2>(a, st);
+  }
   if (brow) {
     TATT_CHECK_ARG((fast_ok<OP_STRIDED, OP_ROWCONTIG>(a)), "tatt_gemm_cat: operands must be 16-byte aligned with K, strides multiples of 4");
     return launch<OP_STRIDED, OP_ROWCONTIG>(a, 1, st);
@@ -923,6 +1069,34 @@ int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, flo
                      accumulate, relu, 0, 0, 0, 0L);
   TATT_LAUNCH_CHECK("conv_splitk_reduce");
   return TATT_OK;
+}
+
+// tatt_conv_fwd (packed weights, see tatt_conv_pack_w) with a BatchNorm fused into the epilogue; partial: cdiv(B*H*W, 128) * 2 * Cout floats.
+//   epi 1: the convolution is FOLLOWED by a BatchNorm in training mode: per-row-block (mean, M2) of Y -> tatt_bn_stats_from_partial
+//   epi 2: the convolution is the input-gradient pass whose result is the output gradient of act(BatchNorm(bn_x)): Y receives
+//          g = dy * act'(bn(bn_x)) and partial the sums (sum g, sum g xhat) -> tatt_bn_bwd_from_partial
+int tatt_conv_fwd_bn(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                     long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int flags, int epi, const float* bn_x,
+                     long bn_ldx, const float* bn_stat, const float* bn_gamma, const float* bn_beta, int bn_act, float* partial,
+                     hipStream_t st) {
+  TATT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && partial && (epi == 1 || epi == 2), "tatt_conv_fwd_bn: bad arguments");
+  TATT_CHECK_ARG(epi == 1 || (bn_x && bn_stat && bn_gamma && bn_beta), "tatt_conv_fwd_bn: epi 2 needs the BatchNorm's x / stat / gamma / beta");
+  TATT_CHECK_ARG(Cin % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)X) & 15) == 0 && (KH & 1) && (KW & 1), "tatt_conv_fwd_bn: Cin/ldx multiples of 4, odd kernels");
+  TATT_CHECK_ARG(w_sci == 1 && (w_sn | w_stap | w_base) % 4 == 0 && (((uintptr_t)Wt) & 15) == 0, "tatt_conv_fwd_bn: packed weights required");
+  TATT_CHECK_ARG((long)B * H * W * ldx * 4 < (1L << 31) && (long)Cout * Cin * KH * KW * 4 < (1L << 31), "tatt_conv_fwd_bn: operands must stay below 2 GiB");
+  GemmArgs a;
+  init_args(a);
+  a.A = X; a.B = Wt; a.C = Y; a.bias = bias;
+  a.M = B * H * W; a.N = Cout; a.K = KH * KW * Cin;
+  a.ldc = ldy;
+  a.splitk = 1;
+  a.kchunk = cdiv(a.K, BK) * BK;
+  a.bf16 = (flags & TATT_BF16) != 0;
+  a.g = ConvGeom{H, W, Cin, KH, KW, KH / 2, KW / 2, (int)ldx};
+  a.w_sn = w_sn; a.w_sci = w_sci; a.w_base = w_base; a.w_stap = w_stap;
+  a.epi_partial = partial; a.epi_C = Cout;
+  a.epi_x = bn_x; a.epi_ldx = bn_ldx; a.epi_stat = bn_stat; a.epi_gamma = bn_gamma; a.epi_beta = bn_beta; a.epi_act = bn_act;
+  return epi == 1 ? launch_epi<OP_IM2COL, OP_CONVW_P, 1>(a, st) : launch_epi<OP_IM2COL, OP_CONVW_P, 2>(a, st);
 }
 
 // Workspace floats of tatt_conv_skinny_fwd: planar Z [T*Cout][B*H*W] + repacked weights [T*Cout][Cin].

@@ -533,6 +533,33 @@ int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const floa
   return TATT_OK;
 }
 
+// Second halves of the BatchNorm passes whose first half ran in a GEMM / convolution epilogue (tatt_conv_fwd_bn, tatt_gemm_cat_bnbwd):
+// partial [nblk][2][C] holds one (mean, M2) resp. (sum g, sum g xhat) pair per block of rows_per_blk rows.
+int tatt_bn_stats_from_partial(const float* partial, int nblk, int rows_per_blk, int R, int C, float eps, float momentum, float* stat,
+                               float* run_mean, float* run_var, hipStream_t st) {
+  TATT_CHECK_ARG(partial && stat && nblk > 0 && rows_per_blk > 0 && (long)nblk * rows_per_blk >= R && (long)(nblk - 1) * rows_per_blk < R && C > 0,
+                 "tatt_bn_stats_from_partial: bad arguments");
+  hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nblk, R, C, rows_per_blk, eps, momentum, stat, run_mean,
+                     run_var);
+  TATT_LAUNCH_CHECK("bn_stats_final");
+  return TATT_OK;
+}
+
+// dx (+)= BatchNorm backward given g = dy * act'(bn(x)) (already multiplied by the activation's derivative) and its partial sums;
+// sums: 2*C floats of scratch.
+int tatt_bn_bwd_from_partial(const float* x, long ldx, const float* g, long ldg, const float* stat, const float* gamma, const float* beta,
+                             const float* partial, int nblk, float* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int train,
+                             int accumulate_params, int accumulate_dx, float* sums, hipStream_t st) {
+  TATT_CHECK_ARG(x && g && stat && gamma && beta && partial && dx && sums && nblk > 0 && C % 4 == 0 && (C <= 256 || C % 256 == 0),
+                 "tatt_bn_bwd_from_partial: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nblk, C, sums, dgamma, dbeta, accumulate_params);
+  TATT_LAUNCH_CHECK("bn_bwd_final");
+  hipLaunchKernelGGL(bn_bwd_apply, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, g, ldg, stat, gamma, beta, sums, dx, lddx, R, C,
+                     0, train, accumulate_dx);
+  TATT_LAUNCH_CHECK("bn_bwd_apply");
+  return TATT_OK;
+}
+
 int tatt_ln_fwd(const float* x, const float* res, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev,
                 const float* gamma,
                 const float* beta, float* vout, float* y, int rows, float eps, hipStream_t st) {

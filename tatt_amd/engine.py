@@ -327,6 +327,45 @@ class Engine:
         self.L.bn_apply(x, C, stat, P[pre + "weight"], P[pre + "bias"], res, C, y, C, R, C, act)
         return y, stat
 
+    # ---- BatchNorm fused into the producing launch (tatt_conv_fwd_bn / tatt_gemm_cat_bnbwd): the row reductions of both passes run
+    # in the epilogue of the convolution / GEMM that writes the tensor, one (mean, M2) or (sum g, sum g xhat) pair per 128-row tile
+    def conv_bn(self, pre_bn, x, W, b, B, H, Wd, Cin, Cout, k, train, act, res=None):
+        """y = act(BatchNorm(conv(x))) (+ res).  Training mode: batch statistics from the convolution's epilogue.
+        Returns (conv output, y, stat)."""
+        P, R, T = self.P, B * H * Wd, k * k
+        c = self.new(R, Cout)
+        if not train:
+            self.conv(x, W, b, c, B, H, Wd, Cin, Cout, k)
+            y, stat = self.bn(pre_bn, c, R, Cout, False, act, res=res)
+            return c, y, stat
+        nblk = -(-R // 128)
+        part = self.new(nblk * 2 * Cout)
+        self.L.conv_fwd_bn(x, self._packed(W, Cout, Cin, k)[0], b, c, B, H, Wd, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, self.pf, 1,
+                           None, 0, None, None, None, 0, part)
+        stat = self.new(2, Cout)
+        self.L.bn_stats_from_partial(part, nblk, 128, R, Cout, 1e-5, 0.1, stat, P[pre_bn + "running_mean"], P[pre_bn + "running_var"])
+        self._nbt.append(P[pre_bn + "num_batches_tracked"])
+        y = self.new(R, Cout)
+        self.L.bn_apply(c, Cout, stat, P[pre_bn + "weight"], P[pre_bn + "bias"], res, Cout, y, Cout, R, Cout, act)
+        return c, y, stat
+
+    def conv_dgrad_bn(self, dy, W, B, H, Wd, Cin, Cout, k, pre_bn, bn_x, stat, act, train, G):
+        """dx through conv^T (forward weight W [Cout,Cin,k,k]) and the act(BatchNorm) in front of the convolution's input:
+        returns (g = conv^T(dy) * act'(bn(bn_x)) -- for act 0 the plain input gradient --, d bn_x)."""
+        P, R, T = self.P, B * H * Wd, k * k
+        g = self.new(R, Cin)
+        nblk = -(-R // 128)
+        part = self.new(nblk * 2 * Cin)
+        self.L.conv_fwd_bn(dy, self._packed(W, Cout, Cin, k)[1], None, g, B, H, Wd, Cout, Cin, k, k, Cout, Cin, T * Cout, 1, 0, Cout, self.pf, 2,
+                           bn_x, Cin, stat, P[pre_bn + "weight"], P[pre_bn + "bias"], act, part)
+        return g, self.bn_bwd_part(pre_bn, bn_x, g, stat, part, nblk, R, Cin, train, G)
+
+    def bn_bwd_part(self, pre, x, g, stat, part, nblk, R, C, train, G):
+        dx = self.new(R, C)
+        self.L.bn_bwd_from_partial(x, C, g, C, stat, self.P[pre + "weight"], self.P[pre + "bias"], part, nblk, dx, C, G[pre + "weight"],
+                                   G[pre + "bias"], R, C, 1 if train else 0, 1, 0, self.new(2 * C))
+        return dx
+
     def bn_bwd(self, pre, x, dy, stat, R, C, act, train, G):
         dx = self.new(R, C)
         self.L.bn_bwd(x, C, dy, C, stat, self.P[pre + "weight"], self.P[pre + "bias"], dx, C, G[pre + "weight"],
@@ -389,8 +428,10 @@ class Engine:
             ctx[key] = (out, sv)
         return out
 
-    def gru_block_bwd(self, pre, dout, inputs, B, H, W, vertical, ctx, key, G):
-        """inputs: list of (x [R,64], dx [R,64], acc) per concatenated input.  Writes parameter grads, input grads into dx."""
+    def gru_block_bwd(self, pre, dout, inputs, B, H, W, vertical, ctx, key, G, bn=None):
+        """inputs: list of (x [R,64], dx [R,64], acc) per concatenated input.  Writes parameter grads, input grads into dx.
+        bn = (pre_bn, bn_x, stat): the first input is the output of that (activation-free) BatchNorm; the GEMM's epilogue then
+        also reduces (sum g, sum g xhat) over its rows and the partial sums are returned (part, nblk) for bn_bwd_part()."""
         P, R, L = self.P, B * H * W, self.L
         out, sv = ctx[key]
         dgi, dgh, hprev = self.new(R, 192), self.new(R, 192), self.new(R, 64)
@@ -416,8 +457,17 @@ class Engine:
         for _, dx, _ in inputs:
             self._guard(dx)
         two = len(inputs) > 1
-        L.gemm_cat(dgi, None, 0, Wf, inputs[0][1], inputs[1][1] if two else None, 64, None, R, Cin, 192, 192, 1, Cin, 64, 64,
-                   inputs[0][2], inputs[1][2] if two else 0, self.pf)
+        if bn is None:
+            L.gemm_cat(dgi, None, 0, Wf, inputs[0][1], inputs[1][1] if two else None, 64, None, R, Cin, 192, 192, 1, Cin, 64, 64,
+                       inputs[0][2], inputs[1][2] if two else 0, self.pf)
+            return None
+        pre_bn, bn_x, stat = bn
+        assert inputs[0][2] == 0
+        nblk = -(-R // 128)
+        part = self.new(nblk * 2 * 64)
+        L.gemm_cat_bnbwd(dgi, None, 0, Wf, inputs[0][1], inputs[1][1] if two else None, 64, None, R, Cin, 192, 192, 1, Cin, 64, 64,
+                         0, inputs[1][2] if two else 0, self.pf, bn_x, 64, stat, P[pre_bn + "weight"], P[pre_bn + "bias"], 0, 64, part)
+        return part, nblk
 
     # ---- attention block pieces ------------------------------------------------------------------------------------
     def mha_fwd(self, pre, q_in, k_in, v_in, B, Lq, cfg):
@@ -634,12 +684,8 @@ class Engine:
         # The first SRB's convolutions (conv-BN-mish-conv-BN, model/tsrn.py:333-338) need block1's output only: they go here,
         # ahead of the decoder, where the main chain would otherwise sit waiting for the RPE chain's query_pos.
         def srb_convs(pre, blk):
-            ca = self.new(R0, 64)
-            self.conv(blk, P[pre + "conv1.weight"], P[pre + "conv1.bias"], ca, B, H, W, 64, 64, 3)
-            ma, st1 = self.bn(pre + "bn1.", ca, R0, 64, training, 2)
-            cb = self.new(R0, 64)
-            self.conv(ma, P[pre + "conv2.weight"], P[pre + "conv2.bias"], cb, B, H, W, 64, 64, 3)
-            r2, st2 = self.bn(pre + "bn2.", cb, R0, 64, training, 0)
+            ca, ma, st1 = self.conv_bn(pre + "bn1.", blk, P[pre + "conv1.weight"], P[pre + "conv1.bias"], B, H, W, 64, 64, 3, training, 2)
+            cb, r2, st2 = self.conv_bn(pre + "bn2.", ma, P[pre + "conv2.weight"], P[pre + "conv2.bias"], B, H, W, 64, 64, 3, training, 0)
             return ca, ma, st1, cb, r2, st2
         first_convs = srb_convs("block2.", b1) if m.srb_nums > 0 else None
 
@@ -681,9 +727,7 @@ class Engine:
 
         # ---- block7 (conv+BN) + global residual, block8 (upsample + 9x9) + sigmoid ---------------------------------------
         k7 = f"block{m.srb_nums + 2}."
-        c7 = self.new(R0, 64)
-        self.conv(blk, P[k7 + "0.weight"], P[k7 + "0.bias"], c7, B, H, W, 64, 64, 3)
-        u_in, st7 = self.bn(k7 + "1.", c7, R0, 64, training, 0, res=b1)
+        c7, u_in, st7 = self.conv_bn(k7 + "1.", blk, P[k7 + "0.weight"], P[k7 + "0.bias"], B, H, W, 64, 64, 3, training, 0, res=b1)
         k8 = f"block{m.srb_nums + 3}."
         cu = self.new(R0, 256)
         self.conv(u_in, P[k8 + "0.conv.weight"], P[k8 + "0.conv.bias"], cu, B, H, W, 64, 256, 3)
@@ -743,9 +787,8 @@ class Engine:
         dcu = self.new(R0, 256)
         L.pixshuf_mish_bwd(cu, dup, dcu, B, H, W, 64)
         self.conv_wgrad(u_in, dcu, G[k8 + "0.conv.weight"], G[k8 + "0.conv.bias"], B, H, W, 64, 256, 3)
-        db1 = self.new(R0, 64)                                               # grad of block1 output, accumulated below
-        self.conv_dgrad(dcu, P[k8 + "0.conv.weight"], db1, B, H, W, 64, 256, 3)
-        dc7 = self.bn_bwd(k7 + "1.", c7, db1, st7, R0, 64, 0, training, G)
+        # grad of block1's output (accumulated below) = grad of u_in = bn(c7) + b1: the BatchNorm's reduction runs in the dgrad epilogue
+        db1, dc7 = self.conv_dgrad_bn(dcu, P[k8 + "0.conv.weight"], B, H, W, 64, 256, 3, k7 + "1.", c7, st7, 0, training, G)
         self.conv_wgrad(blk_last, dc7, G[k7 + "0.weight"], G[k7 + "0.bias"], B, H, W, 64, 64, 3)
         dout = self.new(R0, 64)
         self.conv_dgrad(dc7, P[k7 + "0.weight"], dout, B, H, W, 64, 64, 3)
@@ -760,15 +803,13 @@ class Engine:
             ds = self.new(R0, 64)
             self.gru_block_bwd(pre + "gru2.", dout, [(s, ds, 0)], B, H, W, False, ctx, pre + "gru2", G)
             dr2 = self.new(R0, 64)
-            self.gru_block_bwd(pre + "gru1.", ds, [(r2, dr2, 0), (tp_map, dtp, 0 if first_tp else 1)], B, H, W,
-                               True, ctx, pre + "gru1", G)
+            part, nblk = self.gru_block_bwd(pre + "gru1.", ds, [(r2, dr2, 0), (tp_map, dtp, 0 if first_tp else 1)], B, H, W,
+                                            True, ctx, pre + "gru1", G, bn=(pre + "bn2.", cb, st2))
             first_tp = False
             self._w_flush()
-            dcb = self.bn_bwd(pre + "bn2.", cb, dr2, st2, R0, 64, 0, training, G)
+            dcb = self.bn_bwd_part(pre + "bn2.", cb, dr2, st2, part, nblk, R0, 64, training, G)
             self.conv_wgrad(ma, dcb, G[pre + "conv2.weight"], G[pre + "conv2.bias"], B, H, W, 64, 64, 3)
-            dma = self.new(R0, 64)
-            self.conv_dgrad(dcb, P[pre + "conv2.weight"], dma, B, H, W, 64, 64, 3)
-            dca = self.bn_bwd(pre + "bn1.", ca, dma, st1, R0, 64, 2, training, G)
+            _, dca = self.conv_dgrad_bn(dcb, P[pre + "conv2.weight"], B, H, W, 64, 64, 3, pre + "bn1.", ca, st1, 2, training, G)
             self.conv_wgrad(blk, dca, G[pre + "conv1.weight"], G[pre + "conv1.bias"], B, H, W, 64, 64, 3)
             self.conv_dgrad(dca, P[pre + "conv1.weight"], ds, B, H, W, 64, 64, 3, acc=1)     # dx = ds + conv1^T(dca)
             dout = ds                                            # (no flush here: the conv weight gradients wait for the next SRB's

@@ -593,3 +593,84 @@ def test_gru_fold_and_unfold_vs_autograd(Cin):
     L().gru_unfold_grad(d["dWf"], d["dbf"], d["Wc"], d["bc"], d["wf"], d["wr"], g[0], g[1], g[2], g[3], g[4], g[5], Cin)
     for got, base, leaf, nm in zip(g, g0, (wf, wr, bfw, brv, wc, b_c), ("dW_ih_f", "dW_ih_r", "db_ih_f", "db_ih_r", "dW_c", "db_c")):
         close(got, base.double() + leaf.grad, 2e-6, nm)
+
+
+# ---- BatchNorm fused into conv / GEMM epilogues ------------------------------------------------------------------------------------
+def _mish(t):
+    return t * torch.tanh(F.softplus(t))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 16, 64, 64, 64), (2, 8, 24, 32, 64), (1, 5, 13, 64, 256)])
+def test_conv_fwd_bn_statistics_in_the_epilogue(B, H, W, Cin, Cout):
+    """tatt_conv_fwd_bn(epi 1) + tatt_bn_stats_from_partial = conv followed by train-mode BatchNorm statistics (ragged last row block)."""
+    x, w, b = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=1) / math.sqrt(9 * Cin), rnd(Cout, seed=2)
+    y = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    R_ = B * H * W
+    wf, wd = torch.empty(w.numel(), device="cuda"), torch.empty(w.numel(), device="cuda")
+    L().conv_pack_w(cu(w), wf, wd, Cout, Cin, 3, 3)
+    out = torch.empty(B, H, W, Cout, device="cuda")
+    nblk = -(-R_ // 128)
+    part = torch.full((nblk * 2 * Cout,), float("nan"), device="cuda")
+    L().conv_fwd_bn(cu(x.permute(0, 2, 3, 1)), wf, cu(b), out, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 9 * Cin, 1, 0, Cin, 0, 1,
+                    None, 0, None, None, None, 0, part)
+    close(out.permute(0, 3, 1, 2), y, what="conv")
+    stat, rm, rv = torch.empty(2, Cout, device="cuda"), cu(rnd(Cout, seed=3)), cu(rnd(Cout, seed=4).abs() + 0.5)
+    rm0, rv0 = rm.clone(), rv.clone()
+    L().bn_stats_from_partial(part, nblk, 128, R_, Cout, 1e-5, 0.1, stat, rm, rv)
+    mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+    close(stat[0], mean, 2e-5, "mean")
+    close(stat[1], 1 / torch.sqrt(var + 1e-5), 2e-5, "invstd")
+    close(rm, 0.9 * rm0.cpu().double() + 0.1 * mean, 2e-5, "running_mean")
+    close(rv, 0.9 * rv0.cpu().double() + 0.1 * y.var((0, 2, 3), unbiased=True), 2e-5, "running_var")
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 16, 64, 64, 64), (1, 7, 19, 64, 256)])
+def test_conv_dgrad_with_batchnorm_backward_in_the_epilogue(B, H, W, Cin, Cout, act):
+    """tatt_conv_fwd_bn(epi 2) + tatt_bn_bwd_from_partial against autograd of z = conv(act(BatchNorm_train(x))) in fp64."""
+    x0, w, dz = rnd(B, Cin, H, W) * 1.5 + 0.3, rnd(Cout, Cin, 3, 3, seed=1) / math.sqrt(9 * Cin), rnd(B, Cout, H, W, seed=2)
+    ga0, be0 = 1 + 0.2 * rnd(Cin, seed=3), 0.1 * rnd(Cin, seed=4)
+    x, ga, be = (t.double().requires_grad_(True) for t in (x0, ga0, be0))
+    bn = F.batch_norm(x, None, None, ga, be, True, 0.1, 1e-5)
+    a = bn if act == 0 else (F.relu(bn) if act == 1 else _mish(bn))
+    F.conv2d(a, w.double(), None, padding=1).backward(dz.double())
+    R_ = B * H * W
+    xn = cu(x0.permute(0, 2, 3, 1))
+    stat, ws_ = torch.empty(2, Cin, device="cuda"), ws()
+    L().bn_stats(xn, Cin, R_, Cin, 1e-5, 0.1, stat, None, None, ws_)
+    wf, wd = torch.empty(w.numel(), device="cuda"), torch.empty(w.numel(), device="cuda")
+    L().conv_pack_w(cu(w), wf, wd, Cout, Cin, 3, 3)
+    nblk = -(-R_ // 128)
+    g, part = torch.empty(R_, Cin, device="cuda"), torch.full((nblk * 2 * Cin,), float("nan"), device="cuda")
+    L().conv_fwd_bn(cu(dz.permute(0, 2, 3, 1)), wd, None, g, B, H, W, Cout, Cin, 3, 3, Cout, Cin, 9 * Cout, 1, 0, Cout, 0, 2,
+                    xn, Cin, stat, cu(ga0), cu(be0), act, part)
+    dx, dga, dbe = torch.empty(R_, Cin, device="cuda"), cu(rnd(Cin, seed=5)), cu(rnd(Cin, seed=6))
+    dga0, dbe0 = dga.clone(), dbe.clone()
+    L().bn_bwd_from_partial(xn, Cin, g, Cin, stat, cu(ga0), cu(be0), part, nblk, dx, Cin, dga, dbe, R_, Cin, 1, 1, 0, torch.empty(2 * Cin, device="cuda"))
+    close(dx.view(B, H, W, Cin).permute(0, 3, 1, 2), x.grad, 5e-5, "dx")
+    close(dga - dga0, ga.grad, 5e-5, "dgamma")
+    close(dbe - dbe0, be.grad, 5e-5, "dbeta")
+
+
+def test_gemm_cat_bnbwd_matches_separate_batchnorm_backward():
+    """tatt_gemm_cat_bnbwd: the split input gradient of a GruBlock whose first input is a BatchNorm output -- first destination reduced
+    for that BatchNorm in the epilogue, second destination accumulated as usual -- against autograd in fp64."""
+    M = 3 * 16 * 64 + 40
+    x0, tp0, Wf, dgi = rnd(M, 64) * 1.3 + 0.2, rnd(M, 64, seed=1), rnd(192, 128, seed=2) * 0.1, rnd(M, 192, seed=3)
+    ga0, be0, d2_0 = 1 + 0.2 * rnd(64, seed=4), 0.1 * rnd(64, seed=5), rnd(M, 64, seed=6)
+    x, ga, be, tp = (t.double().requires_grad_(True) for t in (x0, ga0, be0, tp0))
+    bn = F.batch_norm(x, None, None, ga, be, True, 0.1, 1e-5)
+    (torch.cat([bn, tp], 1) @ Wf.double().t()).backward(dgi.double())
+    xg = cu(x0)
+    stat = torch.empty(2, 64, device="cuda")
+    L().bn_stats(xg, 64, M, 64, 1e-5, 0.1, stat, None, None, ws())
+    nblk = -(-M // 128)
+    g, d2, part = torch.empty(M, 64, device="cuda"), cu(d2_0), torch.full((nblk * 128,), float("nan"), device="cuda")
+    L().gemm_cat_bnbwd(cu(dgi), None, 0, cu(Wf), g, d2, 64, None, M, 128, 192, 192, 1, 128, 64, 64, 0, 1, 0, xg, 64, stat, cu(ga0), cu(be0),
+                       0, 64, part)
+    close(d2, d2_0.double() + tp.grad, what="second destination")
+    dx, dga, dbe = torch.empty(M, 64, device="cuda"), torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    L().bn_bwd_from_partial(xg, 64, g, 64, stat, cu(ga0), cu(be0), part, nblk, dx, 64, dga, dbe, M, 64, 1, 1, 0, torch.empty(128, device="cuda"))
+    close(dx, x.grad, 5e-5, "dx")
+    close(dga, ga.grad, 5e-5, "dgamma")
+    close(dbe, be.grad, 5e-5, "dbeta")
