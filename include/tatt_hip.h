@@ -58,12 +58,13 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
 int tatt_gemm_cat(const float* A, const float* A2, int ksplit, const float* B, float* C, float* C2, int nsplit, const float* bias, int M, int N, int K, long sam, long sbn, long sbk, long ldc, long ldc2, int accumulate, int accumulate2, int flags, hipStream_t stream);
 
 /* GruBlock (model/tsrn.py:1075-1092) = Conv2d 1x1 (:1083) directly followed by nn.GRU (:1088): the GRU's input projection of both
- * directions composes with the conv, gi = (W_ih W_c) x + (W_ih b_c + b_ih).  tatt_gru_fold_w builds Wf[192][Cin] / bf[192] for
+ * directions composes with the conv, gi = (W_ih W_c) x + (W_ih b_c + b_ih).  tatt_gru_fold_w builds Wf[192][Cin] (followed in the
+ * same buffer by WcT[Cin][64] = W_c transposed, which tatt_gru_unfold_grad reads: Wf buffers hold 256*Cin floats) / bf[192] for
  * n <= 16 blocks in one launch (HOST arrays of length n; Wih / bih hold 2n pointers: forward, reverse per block);
  * tatt_gru_unfold_grad adds the gradient of (Wf, bf) onto the reference's parameters: dW_ih += dWf W_c^T + dbf b_c^T,
  * db_ih += dbf, dW_c += W_ih^T dWf, db_c += W_ih^T dbf. */
 int tatt_gru_fold_w(int n, const float* const* Wc, const float* const* bc, const float* const* Wih, const float* const* bih, float* const* Wf, float* const* bf, const int* Cin, hipStream_t stream);
-int tatt_gru_unfold_grad(const float* dWf, const float* dbf, const float* Wc, const float* bc, const float* Wih_f, const float* Wih_b, float* dWih_f, float* dWih_b, float* dbih_f, float* dbih_b, float* dWc, float* dbc, int Cin, hipStream_t stream);
+int tatt_gru_unfold_grad(const float* dWf, const float* dbf, const float* WcT, const float* bc, const float* Wih_f, const float* Wih_b, float* dWih_f, float* dWih_b, float* dbih_f, float* dbih_b, float* dWc, float* dbc, int Cin, hipStream_t stream);
 
 /* Weight + bias gradient of a Linear / 1x1 conv with a small output (M <= 96, N <= 64): dW[M,N] += dY[R,M]^T X[R,N],
  * db[M] += colsum(dY) in ONE streaming pass over the R rows (autograd of F.linear at the sites above). */

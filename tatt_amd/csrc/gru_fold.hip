@@ -15,7 +15,7 @@ struct FoldGroup {
   const float* bc[FOLD_MAX];      // [64]
   const float* Wih[FOLD_MAX][2];  // [96][64] forward, reverse
   const float* bih[FOLD_MAX][2];  // [96]
-  float* Wf[FOLD_MAX];            // [192][Cin]
+  float* Wf[FOLD_MAX];            // [192][Cin], followed by WcT [Cin][64] (the conv weight transposed, for the gradient kernel)
   float* bf[FOLD_MAX];            // [192]
   int Cin[FOLD_MAX];
 };
@@ -37,13 +37,16 @@ __global__ __launch_bounds__(256) void gru_fold_w_k(FoldGroup g) {
     float s = g.bih[b][j >= 96][j % 96];
     for (int m = 0; m < 64; ++m) s += wi[m] * g.bc[b][m];
     g.bf[b][j] = s;
+  } else if (i < 192 * Cin + 192 + 64 * Cin) {  // WcT[c][m] = Wc[m][c]
+    const int e = i - 192 * Cin - 192, c = e >> 6, m = e & 63;
+    g.Wf[b][192 * Cin + e] = g.Wc[b][(long)m * Cin + c];
   }
 }
 
 struct UnfoldArgs {
   const float* dWf;  // [192][Cin]
   const float* dbf;  // [192]
-  const float* Wc;   // [64][Cin]
+  const float* WcT;  // [Cin][64] (written by tatt_gru_fold_w behind Wf)
   const float* bc;   // [64]
   const float* Wih[2];
   float* dWih[2];  // [96][64] +=
@@ -58,11 +61,16 @@ __global__ __launch_bounds__(256) void gru_unfold_grad_k(UnfoldArgs u) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i < 192 * 64) {  // dW_ih[j][m] += sum_c dWf[j][c] Wc[m][c] + dbf[j] bc[m]
     const int j = i >> 6, m = i & 63;
-    const float* df = u.dWf + (long)j * Cin;
-    const float* wc = u.Wc + (long)m * Cin;
-    float s = u.dbf[j] * u.bc[m];
-    for (int c = 0; c < Cin; ++c) s += df[c] * wc[c];
-    u.dWih[j >= 96][(j % 96) * 64 + m] += s;
+    const float* df = u.dWf + (long)j * Cin;   // wave-uniform row: scalar loads
+    const float* wc = u.WcT + m;                // consecutive lanes read consecutive floats
+    float s0 = u.dbf[j] * u.bc[m], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int c = 0; c < Cin; c += 4) {          // four independent chains: the loads of a trip are in flight together
+      s0 += df[c] * wc[(long)c * 64];
+      s1 += df[c + 1] * wc[(long)(c + 1) * 64];
+      s2 += df[c + 2] * wc[(long)(c + 2) * 64];
+      s3 += df[c + 3] * wc[(long)(c + 3) * 64];
+    }
+    u.dWih[j >= 96][(j % 96) * 64 + m] += (s0 + s1) + (s2 + s3);
     return;
   }
   i -= 192 * 64;
@@ -73,9 +81,19 @@ __global__ __launch_bounds__(256) void gru_unfold_grad_k(UnfoldArgs u) {
   i -= 192;
   if (i < 64 * Cin) {  // dW_c[m][c] += sum_j W_ih[j][m] dWf[j][c]
     const int m = i / Cin, c = i - m * Cin;
-    float s = 0.f;
-    for (int j = 0; j < 192; ++j) s += u.Wih[j >= 96][(j % 96) * 64 + m] * u.dWf[(long)j * Cin + c];
-    u.dWc[i] += s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const float* wi = u.Wih[d] + m;
+      const float* df = u.dWf + (long)d * 96 * Cin + c;
+      for (int j = 0; j < 96; j += 4) {
+        s0 += wi[j * 64] * df[(long)j * Cin];
+        s1 += wi[(j + 1) * 64] * df[(long)(j + 1) * Cin];
+        s2 += wi[(j + 2) * 64] * df[(long)(j + 2) * Cin];
+        s3 += wi[(j + 3) * 64] * df[(long)(j + 3) * Cin];
+      }
+    }
+    u.dWc[i] += (s0 + s1) + (s2 + s3);
     return;
   }
   i -= 64 * Cin;
@@ -104,16 +122,16 @@ int tatt_gru_fold_w(int n, const float* const* Wc, const float* const* bc, const
     for (int d = 0; d < 2; ++d) { g.Wih[i][d] = Wih[2 * i + d]; g.bih[i][d] = bih[2 * i + d]; }
     if (Cin[i] > mx) mx = Cin[i];
   }
-  hipLaunchKernelGGL(gru_fold_w_k, dim3(cdiv(192 * mx + 192, 256), n), dim3(256), 0, st, g);
+  hipLaunchKernelGGL(gru_fold_w_k, dim3(cdiv(192 * mx + 192 + 64 * mx, 256), n), dim3(256), 0, st, g);
   TATT_LAUNCH_CHECK("gru_fold_w");
   return TATT_OK;
 }
 
-int tatt_gru_unfold_grad(const float* dWf, const float* dbf, const float* Wc, const float* bc, const float* Wih_f, const float* Wih_b,
+int tatt_gru_unfold_grad(const float* dWf, const float* dbf, const float* WcT, const float* bc, const float* Wih_f, const float* Wih_b,
                          float* dWih_f, float* dWih_b, float* dbih_f, float* dbih_b, float* dWc, float* dbc, int Cin, hipStream_t st) {
-  TATT_CHECK_ARG(dWf && dbf && Wc && bc && Wih_f && Wih_b && dWih_f && dWih_b && dbih_f && dbih_b && dWc && dbc && Cin > 0,
+  TATT_CHECK_ARG(dWf && dbf && WcT && bc && Cin % 4 == 0 && Wih_f && Wih_b && dWih_f && dWih_b && dbih_f && dbih_b && dWc && dbc && Cin > 0,
                  "tatt_gru_unfold_grad: bad arguments");
-  UnfoldArgs u{dWf, dbf, Wc, bc, {Wih_f, Wih_b}, {dWih_f, dWih_b}, {dbih_f, dbih_b}, dWc, dbc, Cin};
+  UnfoldArgs u{dWf, dbf, WcT, bc, {Wih_f, Wih_b}, {dWih_f, dWih_b}, {dbih_f, dbih_b}, dWc, dbc, Cin};
   hipLaunchKernelGGL(gru_unfold_grad_k, dim3(cdiv(192 * 64 + 192 + 64 * Cin + 64, 256)), dim3(256), 0, st, u);
   TATT_LAUNCH_CHECK("gru_unfold_grad");
   return TATT_OK;

@@ -93,35 +93,44 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
 }
 
 // stat layout: [2][C] = mean, invstd.  running stats updated with momentum (unbiased var).
-__global__ void bn_stats_final(const float* __restrict__ partial, int nblk, int R, int C, int rows_per_blk, float eps,
-                               float momentum, float* __restrict__ stat, float* __restrict__ run_mean,
-                               float* __restrict__ run_var) {
-  // block = 16 channels x 16 row lanes: each lane Chan-merges a strided subset of the row blocks, lane 0 merges the 16
-  __shared__ float sn[256], sm[256], s2[256];
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+  if (nb == 0.f) return;
+  const float d = mb - mean, nn = n + nb;
+  mean += d * (nb / nn);
+  m2 += m2b + d * d * (n * nb / nn);
+  n = nn;
+}
+
+// block = 16 channels x (blockDim.x / 16) row lanes (64 with 1024 threads: the conv epilogues leave one partial per 128 rows, 512 of
+// them at B = 64): each lane Chan-merges a strided subset of the row blocks, then 8 lanes merge 8 lanes each, then lane 0 those 8
+__global__ __launch_bounds__(1024) void bn_stats_final(const float* __restrict__ partial, int nblk, int R, int C, int rows_per_blk, float eps,
+                                                        float momentum, float* __restrict__ stat, float* __restrict__ run_mean,
+                                                        float* __restrict__ run_var) {
+  __shared__ float sn[1024], sm[1024], s2[1024];
+  const int RLN = blockDim.x >> 4;
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   float n = 0.f, mean = 0.f, m2 = 0.f;
   if (c < C)
-    for (int b = rl; b < nblk; b += 16) {
-      float nb = (float)(min(R, (b + 1) * rows_per_blk) - b * rows_per_blk);
-      float mb = partial[((long)b * 2 + 0) * C + c], m2b = partial[((long)b * 2 + 1) * C + c];
-      float d = mb - mean, nn = n + nb;
-      mean += d * (nb / nn);
-      m2 += m2b + d * d * (n * nb / nn);
-      n = nn;
+    for (int b = rl; b < nblk; b += RLN) {
+      const float nb = (float)(min(R, (b + 1) * rows_per_blk) - b * rows_per_blk);
+      chan_merge(n, mean, m2, nb, partial[((long)b * 2 + 0) * C + c], partial[((long)b * 2 + 1) * C + c]);
     }
   sn[threadIdx.x] = n; sm[threadIdx.x] = mean; s2[threadIdx.x] = m2;
   __syncthreads();
+  if (RLN > 8) {  // second level: lanes 0..7 merge every 8th lane's result
+    if (rl < 8) {
+      n = 0.f; mean = 0.f; m2 = 0.f;
+      for (int j = rl; j < RLN; j += 8) chan_merge(n, mean, m2, sn[j * 16 + cl], sm[j * 16 + cl], s2[j * 16 + cl]);
+    }
+    __syncthreads();
+    if (rl < 8) { sn[threadIdx.x] = n; sm[threadIdx.x] = mean; s2[threadIdx.x] = m2; }
+    __syncthreads();
+  }
   if (rl != 0 || c >= C) return;
   n = 0.f; mean = 0.f; m2 = 0.f;
-  for (int j = 0; j < 16; ++j) {
-    float nb = sn[j * 16 + cl];
-    if (nb == 0.f) continue;
-    float d = sm[j * 16 + cl] - mean, nn = n + nb;
-    mean += d * (nb / nn);
-    m2 += s2[j * 16 + cl] + d * d * (n * nb / nn);
-    n = nn;
-  }
+  const int last = RLN > 8 ? 8 : RLN;
+  for (int j = 0; j < last; ++j) chan_merge(n, mean, m2, sn[j * 16 + cl], sm[j * 16 + cl], s2[j * 16 + cl]);
   float var = m2 / n;
   stat[c] = mean;
   stat[C + c] = rsqrtf(var + eps);
@@ -284,14 +293,42 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ x
   }
 }
 
-// sums[2][C]; dgamma/dbeta (+)=
-__global__ void bn_bwd_final(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums,
-                             float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-  __shared__ float red[256];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-  float s1 = block16_colsum(partial, nblk, 2L * C, c, c < C, red);
-  float s2 = block16_colsum(partial + C, nblk, 2L * C, c, c < C, red);
-  if (threadIdx.x >= 16 || c >= C) return;
+// sums[2][C]; dgamma/dbeta (+)=.  block = 16 channels x (blockDim.x / 16) row lanes, every lane's loads independent of one another
+__global__ __launch_bounds__(1024) void bn_bwd_final(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  __shared__ float r1[1024], r2[1024];
+  const int RLN = blockDim.x >> 4;
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+  if (c < C) {
+    int b = rl;
+    for (; b + RLN < nblk; b += 2 * RLN) {
+      a1 += partial[((long)b * 2 + 0) * C + c];
+      a2 += partial[((long)b * 2 + 1) * C + c];
+      b1 += partial[((long)(b + RLN) * 2 + 0) * C + c];
+      b2 += partial[((long)(b + RLN) * 2 + 1) * C + c];
+    }
+    if (b < nblk) {
+      a1 += partial[((long)b * 2 + 0) * C + c];
+      a2 += partial[((long)b * 2 + 1) * C + c];
+    }
+  }
+  r1[threadIdx.x] = a1 + b1;
+  r2[threadIdx.x] = a2 + b2;
+  __syncthreads();
+  if (RLN > 8) {
+    float t1 = 0.f, t2 = 0.f;
+    if (rl < 8)
+      for (int j = rl; j < RLN; j += 8) { t1 += r1[j * 16 + cl]; t2 += r2[j * 16 + cl]; }
+    __syncthreads();
+    if (rl < 8) { r1[threadIdx.x] = t1; r2[threadIdx.x] = t2; }
+    __syncthreads();
+  }
+  if (rl != 0 || c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  const int last = RLN > 8 ? 8 : RLN;
+  for (int j = 0; j < last; ++j) { s1 += r1[j * 16 + cl]; s2 += r2[j * 16 + cl]; }
   sums[c] = s1;
   sums[C + c] = s2;
   if (dgamma) {
@@ -495,7 +532,7 @@ int tatt_bn_stats(const float* x, long ldx, int R, int C, float eps, float momen
   bn_blocking(R, &nblk, &rpb);
   hipLaunchKernelGGL(bn_stats_partial, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, rpb, workspace);
   TATT_LAUNCH_CHECK("bn_stats_partial");
-  hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, 16)), dim3(256), 0, st, workspace, nblk, R, C, rpb, eps, momentum, stat, run_mean,
+  hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, 16)), dim3(nblk > 128 ? 1024 : 256), 0, st, workspace, nblk, R, C, rpb, eps, momentum, stat, run_mean,
                      run_var);
   TATT_LAUNCH_CHECK("bn_stats_final");
   return TATT_OK;
@@ -525,7 +562,7 @@ int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const floa
   float* sums = workspace + (size_t)BN_MAXBLK * 2 * C;
   hipLaunchKernelGGL(bn_bwd_reduce, dim3(nblk), dim3(256), 0, st, x, ldx, dy, lddy, stat, gamma, beta, R, C, act, rpb, workspace);
   TATT_LAUNCH_CHECK("bn_bwd_reduce");
-  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 16)), dim3(256), 0, st, workspace, nblk, C, sums, dgamma, dbeta, accumulate_params);
+  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 16)), dim3(nblk > 128 ? 1024 : 256), 0, st, workspace, nblk, C, sums, dgamma, dbeta, accumulate_params);
   TATT_LAUNCH_CHECK("bn_bwd_final");
   hipLaunchKernelGGL(bn_bwd_apply, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, dy, lddy, stat, gamma, beta, sums, dx, lddx, R, C,
                      act, train, accumulate_dx);
@@ -539,7 +576,7 @@ int tatt_bn_stats_from_partial(const float* partial, int nblk, int rows_per_blk,
                                float* run_mean, float* run_var, hipStream_t st) {
   TATT_CHECK_ARG(partial && stat && nblk > 0 && rows_per_blk > 0 && (long)nblk * rows_per_blk >= R && (long)(nblk - 1) * rows_per_blk < R && C > 0,
                  "tatt_bn_stats_from_partial: bad arguments");
-  hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nblk, R, C, rows_per_blk, eps, momentum, stat, run_mean,
+  hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, 16)), dim3(nblk > 128 ? 1024 : 256), 0, st, partial, nblk, R, C, rows_per_blk, eps, momentum, stat, run_mean,
                      run_var);
   TATT_LAUNCH_CHECK("bn_stats_final");
   return TATT_OK;
@@ -552,7 +589,7 @@ int tatt_bn_bwd_from_partial(const float* x, long ldx, const float* g, long ldg,
                              int accumulate_params, int accumulate_dx, float* sums, hipStream_t st) {
   TATT_CHECK_ARG(x && g && stat && gamma && beta && partial && dx && sums && nblk > 0 && C % 4 == 0 && (C <= 256 || C % 256 == 0),
                  "tatt_bn_bwd_from_partial: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nblk, C, sums, dgamma, dbeta, accumulate_params);
+  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 16)), dim3(nblk > 128 ? 1024 : 256), 0, st, partial, nblk, C, sums, dgamma, dbeta, accumulate_params);
   TATT_LAUNCH_CHECK("bn_bwd_final");
   hipLaunchKernelGGL(bn_bwd_apply, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, g, ldg, stat, gamma, beta, sums, dx, lddx, R, C,
                      0, train, accumulate_dx);

@@ -64,10 +64,14 @@ class Engine:
         # hides), one fork per half SRB 12.23.  Upper bound if the 3.8 ms of weight-gradient kernels were free: 8.99.
         # Matrix-core precision of THIS engine's launches (a per-call flag of the C-ABI, no process state): 0 = exact fp32 operands,
         # TATT_BF16 = operands rounded to bf16 into the MFMA, fp32 accumulate.  Set per forward call from module.matmul_precision
-        # and kept in the call's context for its backward pass.  The STN head, the TPS matrices and the recurrent positional
-        # encoding stay fp32 in both modes (self.pf is not applied there): control points are scaled x64 into pixel coordinates
-        # by grid_sample and the RPE feeds every query, so their rounding error is amplified instead of averaged out.
-        self.pf = 0
+        # and kept in the call's context for its backward pass.  self.pf: the 3x3 convolutions of the trunk (SRBs, block7, the
+        # up-sampling conv; forward, input and weight gradients) -- 85 % of the step's FLOPs, the launches that are matrix-core bound.
+        # self.pl: Linear / 1x1 / GRU-projection GEMMs: always 0.  With K = 64..192 they are bound by moving their fp32 tensors, so
+        # bf16 operands buy no time there, and measured at B=4 they carry most of the mode's error (output max-abs 1.4e-2 with them
+        # in bf16, 6e-3 without).  The STN head, the TPS matrices, the recurrent positional encoding and the output convolution are
+        # fp32 in both modes too: control points are scaled x64 into pixel coordinates by grid_sample, the RPE feeds every query,
+        # the output conv feeds the sigmoid directly -- their rounding error is amplified instead of averaged out.
+        self.pf, self.pl = 0, 0
         self.wgrad_mode = os.environ.get("TATT_WGRAD_STREAM", "batch")
         if self.wgrad_mode not in ("batch", "off"):
             raise RuntimeError("TATT_WGRAD_STREAM must be 'batch' or 'off'")
@@ -186,19 +190,19 @@ class Engine:
 
     def linear(self, x, W, b, out, R, N, K, ldx=None, ldw=None, ldc=None, acc=0, relu=0, splitk=1, fp32=False):
         """out[R,N] (+)= x[R,K] @ W[N,K]^T + b   (splitk > 1 for the few-row, long-K products of the RPE)"""
-        self.L.gemm(x, W, out, b, R, N, K, ldx or K, 1, ldw or K, 1, ldc or N, 1, 0, 0, 0, acc, relu | (0 if fp32 else self.pf),
+        self.L.gemm(x, W, out, b, R, N, K, ldx or K, 1, ldw or K, 1, ldc or N, 1, 0, 0, 0, acc, relu | (0 if fp32 else self.pl),
                     splitk, self.ws if splitk > 1 else None)
 
     def linear_dx(self, dy, W, dx, R, N, K, lddy=None, ldw=None, lddx=None, acc=0, splitk=1, fp32=False):
         """dx[R,K] (+)= dy[R,N] @ W[N,K]"""
         self._guard(dx)
-        self.L.gemm(dy, W, dx, None, R, K, N, lddy or N, 1, 1, ldw or K, lddx or K, 1, 0, 0, 0, acc, 0 if fp32 else self.pf, splitk,
+        self.L.gemm(dy, W, dx, None, R, K, N, lddy or N, 1, 1, ldw or K, lddx or K, 1, 0, 0, 0, acc, 0 if fp32 else self.pl, splitk,
                     self.ws if splitk > 1 else None)
 
     def linear_dw(self, dy, x, dW, R, N, K, lddy=None, ldx=None, lddw=None, fp32=False):
         """dW[N,K] += dy[R,N]^T @ x[R,K]  (always accumulates into the gradient buffer)"""
         sk = self._splitk(N, K, R)
-        fl = 0 if fp32 else self.pf
+        fl = 0 if fp32 else self.pl
         self._wgrad(lambda ws: self.L.gemm(dy, x, dW, None, N, K, R, 1, lddy or N, 1, ldx or K, lddw or K, 1, 0, 0, 0, 1, fl, sk,
                                            ws if sk > 1 else None), [dy], [x])
 
@@ -396,11 +400,11 @@ class Engine:
             pres = [f"block{i + 2}.gru{j}." for i in range(self.m.srb_nums) for j in (1, 2)]
             n = len(pres)
             cin = [P[pre + "conv1.weight"].shape[1] for pre in pres]
-            buf = self.new(sum(192 * c + 192 for c in cin))
+            buf = self.new(sum(256 * c + 192 for c in cin))      # per block: Wf [192][Cin], WcT [Cin][64], bf [192]
             pk, o = {}, 0
             for pre, c in zip(pres, cin):
-                pk[pre] = (buf[o:o + 192 * c].view(192, c), buf[o + 192 * c:o + 192 * c + 192])
-                o += 192 * c + 192
+                pk[pre] = (buf[o:o + 192 * c].view(192, c), buf[o + 256 * c:o + 256 * c + 192], buf[o + 192 * c:o + 256 * c])
+                o += 256 * c + 192
             VP = ctypes.c_void_p
             ptr = lambda ts: [t.data_ptr() for t in ts]
             self.L.gru_fold_w(n, (VP * n)(*ptr([P[pre + "conv1.weight"] for pre in pres])), (VP * n)(*ptr([P[pre + "conv1.bias"] for pre in pres])),
@@ -414,12 +418,12 @@ class Engine:
     def gru_block_fwd(self, pre, inputs, B, H, W, vertical, save, ctx, key):
         """inputs: one or two [R,64] tensors whose channel concatenation is the block's input.  Returns out [R,64]."""
         P, R = self.P, B * H * W
-        Wf, bf = self._gru_fold()[pre]
+        Wf, bf, _ = self._gru_fold()[pre]
         Cin = Wf.shape[1]
         assert Cin == 64 * len(inputs)
         gi = self.new(R, 192)
         self.L.gemm_cat(inputs[0], inputs[1] if len(inputs) > 1 else None, 64, Wf, gi, None, 0, bf, R, 192, Cin, 64, Cin, 1, 192, 0,
-                        0, 0, self.pf)
+                        0, 0, self.pl)
         out = self.new(R, 64)
         sv = self.new(R, 2, 4, 32) if save else None
         self.L.gru32_fwd(gi, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], P[pre + "gru.bias_hh_l0"],
@@ -437,7 +441,7 @@ class Engine:
         dgi, dgh, hprev = self.new(R, 192), self.new(R, 192), self.new(R, 64)
         L.gru32_bwd(dout, out, sv, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], dgi, dgh, hprev,
                     *self._seqmap(B, H, W, vertical))
-        Wf, _ = self._gru_fold()[pre]
+        Wf, _, WcT = self._gru_fold()[pre]
         Cin = Wf.shape[1]
         tmp = self.zeros(192 * Cin + 192)                     # gradient of the composed (Wf, bf); unfolded onto W_ih, W_c, biases below
         dWf, dbf = tmp[:192 * Cin], tmp[192 * Cin:]
@@ -449,7 +453,7 @@ class Engine:
                 wg.append((gi_d, x, dWf[96 * d * Cin + 64 * s:], dbf[96 * d:] if s == 0 else None, R, 96, 64, 192, None, Cin))
         self.linear_dwb_group(wg)                             # queued before the input gradients below may update a dx in place
         sfxs = ("", "_reverse")
-        self._wgrad(lambda ws: L.gru_unfold_grad(dWf, dbf, P[pre + "conv1.weight"], P[pre + "conv1.bias"],
+        self._wgrad(lambda ws: L.gru_unfold_grad(dWf, dbf, WcT, P[pre + "conv1.bias"],
                                                  *[P[pre + "gru.weight_ih_l0" + x] for x in sfxs],
                                                  *[G[pre + "gru.weight_ih_l0" + x] for x in sfxs],
                                                  *[G[pre + "gru.bias_ih_l0" + x] for x in sfxs],
@@ -459,14 +463,14 @@ class Engine:
         two = len(inputs) > 1
         if bn is None:
             L.gemm_cat(dgi, None, 0, Wf, inputs[0][1], inputs[1][1] if two else None, 64, None, R, Cin, 192, 192, 1, Cin, 64, 64,
-                       inputs[0][2], inputs[1][2] if two else 0, self.pf)
+                       inputs[0][2], inputs[1][2] if two else 0, self.pl)
             return None
         pre_bn, bn_x, stat = bn
         assert inputs[0][2] == 0
         nblk = -(-R // 128)
         part = self.new(nblk * 2 * 64)
         L.gemm_cat_bnbwd(dgi, None, 0, Wf, inputs[0][1], inputs[1][1] if two else None, 64, None, R, Cin, 192, 192, 1, Cin, 64, 64,
-                         0, inputs[1][2] if two else 0, self.pf, bn_x, 64, stat, P[pre_bn + "weight"], P[pre_bn + "bias"], 0, 64, part)
+                         0, inputs[1][2] if two else 0, self.pl, bn_x, 64, stat, P[pre_bn + "weight"], P[pre_bn + "bias"], 0, 64, part)
         return part, nblk
 
     # ---- attention block pieces ------------------------------------------------------------------------------------

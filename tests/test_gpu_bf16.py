@@ -117,6 +117,10 @@ def test_model_forward_backward_within_bf16_tolerance():
     cos_ac = float((gac @ g64) / (gac.norm() * g64.norm()))
     print(f"bf16 HIP: max-abs {d:.3e} rel-L2 {r:.3e} grad cos {cos:.5f} | autocast oracle: {d_ac:.3e} {r_ac:.3e} {cos_ac:.5f}")
     assert d > 1e-5                                           # it is not the fp32 path
-    assert d <= max(1e-2, d_ac) and r <= max(1e-2, r_ac), (d, r, d_ac, r_ac)
-    assert abs(loss.item() - loss64.item()) <= 2e-2 * abs(loss64.item())
-    assert cos >= min(0.999, cos_ac), (cos, cos_ac)
+    # SURVEY 8c's bf16 tolerances, as stated (no yardstick clause): output max-abs and rel-L2 <= 1e-2, gradient cosine >= 0.999.
+    # Met because the layers whose rounding error is amplified rather than averaged -- STN head / TPS (x64 into pixel coordinates),
+    # the recurrent positional encoding, the output convolution in front of the sigmoid -- keep fp32 operands in bf16 mode.
+    assert d <= 1e-2 and r <= 1e-2, (d, r)
+    assert abs(loss.item() - loss64.item()) <= 1e-2 * abs(loss64.item())
+    assert cos >= 0.999, cos
+    assert d < d_ac and cos > cos_ac                           # and far inside what stock autocast(bfloat16) gives on this network

@@ -582,15 +582,17 @@ def test_gru_fold_and_unfold_vs_autograd(Cin):
     ((Wf_ref * dWf.double()).sum() + (bf_ref * dbf.double()).sum()).backward()
     VP = ctypes.c_void_p
     d = {k: cu(v) for k, v in dict(Wc=Wc, bc=bc, wf=Wih[0], wr=Wih[1], bf_=bih[0], br=bih[1], dWf=dWf, dbf=dbf).items()}
-    Wf, bf = torch.empty(192, Cin, device="cuda"), torch.empty(192, device="cuda")
+    Wf, bf = torch.empty(256, Cin, device="cuda"), torch.empty(192, device="cuda")      # Wf [192][Cin] + WcT [Cin][64]
     p = lambda *ts: [t.data_ptr() for t in ts]
     L().gru_fold_w(1, (VP * 1)(*p(d["Wc"])), (VP * 1)(*p(d["bc"])), (VP * 2)(*p(d["wf"], d["wr"])), (VP * 2)(*p(d["bf_"], d["br"])),
                    (VP * 1)(*p(Wf)), (VP * 1)(*p(bf)), (ctypes.c_int * 1)(Cin))
-    close(Wf, Wf_ref, 2e-6, "Wf")
+    close(Wf[:192], Wf_ref, 2e-6, "Wf")
+    WcT = Wf.view(-1)[192 * Cin:]
+    assert torch.equal(WcT.view(Cin, 64).cpu(), Wc.t())
     close(bf, bf_ref, 2e-6, "bf")
     g0 = [rnd(*t.shape, seed=20 + i) for i, t in enumerate((Wih[0], Wih[1], bih[0], bih[1], Wc, bc))]       # += onto existing gradients
     g = [cu(t) for t in g0]
-    L().gru_unfold_grad(d["dWf"], d["dbf"], d["Wc"], d["bc"], d["wf"], d["wr"], g[0], g[1], g[2], g[3], g[4], g[5], Cin)
+    L().gru_unfold_grad(d["dWf"], d["dbf"], WcT, d["bc"], d["wf"], d["wr"], g[0], g[1], g[2], g[3], g[4], g[5], Cin)
     for got, base, leaf, nm in zip(g, g0, (wf, wr, bfw, brv, wc, b_c), ("dW_ih_f", "dW_ih_r", "db_ih_f", "db_ih_r", "dW_c", "db_c")):
         close(got, base.double() + leaf.grad, 2e-6, nm)
 
