@@ -710,24 +710,43 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
 
 // sum slabs: dst[perm(i)] (+)= bias? + sum_z slab[z][i]
 // perm mode 0: identity over [M,N] with ldc; mode 1: conv weight (co, tap, ci) -> OIHW (co, ci, tap)
-__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, float* __restrict__ dst,
+// ZL threads share one output element: a workgroup covers 256 / ZL consecutive elements (a 128-byte run per slab row for ZL = 8),
+// thread group zl sums slabs zl, zl + ZL, ... with independent loads and the ZL partial sums are combined through LDS -- with one
+// thread per element the 36k-element weight gradients of the 3x3 convolutions filled 144 workgroups that each walked 154 slabs in
+// sequence.
+template <int ZL>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, float* __restrict__ dst,
                                      const float* __restrict__ bias, int M, int N, long ldc, int accumulate, int relu,
                                      int perm, int Cin, int T, long dst_batch_stride) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)M * N) return;
+  constexpr int EPB = 256 / ZL;  // elements per workgroup
+  __shared__ float red[256];
+  const long i = (long)blockIdx.x * EPB + (threadIdx.x % EPB);
+  const int zl = threadIdx.x / EPB;
+  const bool on = i < (long)M * N;
   // blockIdx.y = batch index: slabs [batch][nslab][M*N], dst advanced by dst_batch_stride
   slabs += (long)blockIdx.y * nslab * slab_stride;
   dst += (long)blockIdx.y * dst_batch_stride;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // independent chains so that the loads overlap
-  int z = 0;
-  for (; z + 4 <= nslab; z += 4) {
-    s0 += slabs[(z + 0) * slab_stride + i];
-    s1 += slabs[(z + 1) * slab_stride + i];
-    s2 += slabs[(z + 2) * slab_stride + i];
-    s3 += slabs[(z + 3) * slab_stride + i];
+  if (on) {
+    int z = zl;
+    for (; z + 3 * ZL < nslab; z += 4 * ZL) {
+      s0 += slabs[(long)(z + 0 * ZL) * slab_stride + i];
+      s1 += slabs[(long)(z + 1 * ZL) * slab_stride + i];
+      s2 += slabs[(long)(z + 2 * ZL) * slab_stride + i];
+      s3 += slabs[(long)(z + 3 * ZL) * slab_stride + i];
+    }
+    for (; z < nslab; z += ZL) s0 += slabs[(long)z * slab_stride + i];
   }
-  for (; z < nslab; ++z) s0 += slabs[z * slab_stride + i];
   float s = (s0 + s1) + (s2 + s3);
+  if (ZL > 1) {
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (zl != 0) return;
+    s = 0.f;
+#pragma unroll
+    for (int l = 0; l < ZL; ++l) s += red[l * EPB + threadIdx.x];
+  }
+  if (!on) return;
   int m = (int)(i / N), n = (int)(i - (long)m * N);
   long o;
   if (perm == 1) {
@@ -746,6 +765,18 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_
   if (accumulate) s += dst[o];
   if (relu) s = fmaxf(s, 0.f);
   dst[o] = s;
+}
+
+// few outputs and many slabs (weight gradients): 8 lanes per element; otherwise one thread per element
+inline void launch_splitk_reduce(hipStream_t st, int batch, const float* slabs, long slab_stride, int nslab, float* dst, const float* bias,
+                                 int M, int N, long ldc, int accumulate, int relu, int perm, int Cin, int T, long dst_batch_stride) {
+  const long tot = (long)M * N;
+  if (nslab >= 32 && tot <= 262144)
+    hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(cdiv(tot, 32), batch), dim3(256), 0, st, slabs, slab_stride, nslab, dst, bias, M, N, ldc,
+                       accumulate, relu, perm, Cin, T, dst_batch_stride);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cdiv(tot, 256), batch), dim3(256), 0, st, slabs, slab_stride, nslab, dst, bias, M, N, ldc,
+                       accumulate, relu, perm, Cin, T, dst_batch_stride);
 }
 
 // ---- skinny-Cout convolution (Cout <= 16: the 9x9 64->4 output conv and the 9x9 dgrad of block1) ----------------
@@ -824,6 +855,110 @@ __global__ __launch_bounds__(256) void skinny_gather(const float* __restrict__ Z
   float* dst = Y + p * ldy;
 #pragma unroll
   for (int c = 0; c < COUT; ++c) dst[c] = accumulate ? dst[c] + acc[c] : acc[c];
+}
+
+// ---- direct 9x9 convolution with FOUR output channels (the 64 -> 4 output conv, model/tsrn.py:625, and the input gradient of the
+// 9x9 4 -> 64 conv of block1, :598) ------------------------------------------------------------------------------------------
+// With Cout = 4 every input value feeds only four multiply-adds per tap: on the matrix core 15/16 of a 64-wide tile would be padding,
+// and the planar-GEMM detour above (Z[(tap,co)][pixel], then a shifted gather) moves 324 floats per pixel through memory (340 MB at
+// B = 64).  fp32 FMA on the vector ALU has the same peak as fp32 MFMA on this chip, so the convolution runs there directly:
+//   * a workgroup owns a 4 x 64 pixel tile of one image; its four waves split the input channels (wave w takes channel quad w of
+//     every 16-channel chunk) and are summed through LDS at the end;
+//   * per chunk the tile + halo (12 x 72 pixels x 16 channels) is staged in LDS as [quad][row][col] float4, one pad slot per four
+//     columns so that the 16 lanes of a ds_read_b128 pass (four columns apart) hit distinct banks;
+//   * a thread computes 4 consecutive pixels x 4 output channels: per tap row it reads its 12-column window once (12 float4) and
+//     reuses it for the nine horizontal taps from registers -- 576 FMAs per 12 LDS reads;
+//   * the weights are wave-uniform: packed as [quad][tap][ci][co] they arrive by scalar loads and enter v_fma as SGPR operands.
+constexpr int C4_KS = 9, C4_HALO = 4, C4_TH = 4, C4_TW = 64, C4_PX = 4;
+constexpr int C4_RW = C4_TW + 2 * C4_HALO, C4_RWP = C4_RW + C4_RW / 4, C4_RH = C4_TH + 2 * C4_HALO;
+
+__global__ void conv_c4_pack_w(const float* __restrict__ Wt, float* __restrict__ Wp, int Cin, int T, long w_sn, long w_sci, long w_base,
+                               long w_stap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // ((quad * T + tap) * 4 + ci4) * 4 + co
+  if (i >= Cin * T * 4) return;
+  const int co = i & 3, ci4 = (i >> 2) & 3, tap = (i >> 4) % T, q = (i >> 4) / T;
+  Wp[i] = Wt[(long)co * w_sn + (long)(q * 4 + ci4) * w_sci + w_base + (long)tap * w_stap];
+}
+
+__global__ __launch_bounds__(256, 2) void conv_c4_direct(const float* __restrict__ X, long ldx, const float* __restrict__ Wp,
+                                                         const float* __restrict__ bias, float* __restrict__ Y, long ldy, int H, int W,
+                                                         int Cin, int tiles_x, int tiles_y, int accumulate) {
+  __shared__ float4 tile[4 * C4_RH * C4_RWP];  // 69,120 bytes: two workgroups per CU
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y, b = t / tiles_y;
+  const int y0 = ty * C4_TH, x0 = tx * C4_TW;
+  const int gy = lane >> 4, gx = (lane & 15) * C4_PX;  // this thread's pixels: row y0 + gy, columns x0 + gx .. + 3
+  const float* Xb = X + (long)b * H * W * ldx;
+  float acc[C4_PX][4];
+#pragma unroll
+  for (int p = 0; p < C4_PX; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
+  const int nchunk = Cin >> 4;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    __syncthreads();  // the previous chunk's window reads are done
+    for (int i = tid; i < C4_RH * C4_RW * 4; i += 256) {
+      const int q = i & 3, pos = i >> 2, r = pos / C4_RW, c = pos - r * C4_RW;
+      const int yy = y0 + r - C4_HALO, xx = x0 + c - C4_HALO;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+        v = *reinterpret_cast<const float4*>(Xb + ((long)yy * W + xx) * ldx + ch * 16 + q * 4);
+      tile[(q * C4_RH + r) * C4_RWP + c + (c >> 2)] = v;
+    }
+    __syncthreads();
+    const float* __restrict__ wq = Wp + (long)((ch * 4 + wave) * C4_KS * C4_KS) * 16;
+    const float4* trow = tile + (wave * C4_RH + gy) * C4_RWP;
+#pragma unroll 1
+    for (int dy = 0; dy < C4_KS; ++dy) {
+      float4 win[C4_PX + C4_KS - 1];
+#pragma unroll
+      for (int j = 0; j < C4_PX + C4_KS - 1; ++j) win[j] = trow[dy * C4_RWP + (gx + j) + ((gx + j) >> 2)];
+      const float* __restrict__ wr = wq + dy * C4_KS * 16;
+#pragma unroll
+      for (int dx = 0; dx < C4_KS; ++dx) {
+        const float* __restrict__ w = wr + dx * 16;  // [ci4][co]: wave-uniform -> scalar loads, SGPR operands
+#pragma unroll
+        for (int p = 0; p < C4_PX; ++p)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float a = acc[p][c];
+            a = fmaf(win[p + dx].x, w[c], a);
+            a = fmaf(win[p + dx].y, w[4 + c], a);
+            a = fmaf(win[p + dx].z, w[8 + c], a);
+            a = fmaf(win[p + dx].w, w[12 + c], a);
+            acc[p][c] = a;
+          }
+      }
+    }
+  }
+  // sum the four waves' channel partitions: [wave][pixel of the tile][co]
+  __syncthreads();
+  float4* red = tile;
+#pragma unroll
+  for (int p = 0; p < C4_PX; ++p) red[(wave * 256) + lane * C4_PX + p] = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+  __syncthreads();
+  // thread tid finishes pixel tid of the tile (pixel index = lane_of_owner * 4 + p = (row * 16 + colgroup) * 4 + p = row * 64 + col)
+  const int py = tid >> 6, px = tid & 63;
+  const int yy = y0 + py, xx = x0 + px;
+  if (yy >= H || xx >= W) return;
+  float4 s = red[tid];
+#pragma unroll
+  for (int w2 = 1; w2 < 4; ++w2) {
+    const float4 v = red[w2 * 256 + tid];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (bias) { s.x += bias[0]; s.y += bias[1]; s.z += bias[2]; s.w += bias[3]; }
+  float* dst = Y + ((long)(b * H + yy) * W + xx) * ldy;
+  if (accumulate) { s.x += dst[0]; s.y += dst[1]; s.z += dst[2]; s.w += dst[3]; }
+  dst[0] = s.x; dst[1] = s.y; dst[2] = s.z; dst[3] = s.w;
+}
+
+inline bool c4_direct_ok(int Cin, int Cout, int KH, int KW, long ldx, const void* X) {
+  return Cout == 4 && KH == C4_KS && KW == C4_KS && Cin % 16 == 0 && ldx % 4 == 0 && (((uintptr_t)X) & 15) == 0;
 }
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -958,9 +1093,7 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
   else rc = launch<OP_ROWCONTIG, OP_ROWCONTIG>(a, batch, st);
   if (rc) return rc;
   if (splitk > 1) {
-    long tot = (long)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256), batch), dim3(256), 0, st, workspace, (long)M * N, splitk, C, bias,
-                       M, N, ldc, accumulate, relu, 0, 0, 0, sCb);
+    launch_splitk_reduce(st, batch, workspace, (long)M * N, splitk, C, bias, M, N, ldc, accumulate, relu, 0, 0, 0, sCb);
     TATT_LAUNCH_CHECK("splitk_reduce");
   }
   return TATT_OK;
@@ -1065,8 +1198,7 @@ int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, flo
   else rc = launch<OP_IM2COL, OP_CONVW>(a, 1, st);
   if (rc || splitk == 1) return rc;
   const long tot = (long)a.M * Cout;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256), 1), dim3(256), 0, st, workspace, tot, splitk, Y, bias, a.M, Cout, ldy,
-                     accumulate, relu, 0, 0, 0, 0L);
+  launch_splitk_reduce(st, 1, workspace, tot, splitk, Y, bias, a.M, Cout, ldy, accumulate, relu, 0, 0, 0, 0L);
   TATT_LAUNCH_CHECK("conv_splitk_reduce");
   return TATT_OK;
 }
@@ -1101,6 +1233,7 @@ int tatt_conv_fwd_bn(const float* X, const float* Wt, const float* bias, float* 
 
 // Workspace floats of tatt_conv_skinny_fwd: planar Z [T*Cout][B*H*W] + repacked weights [T*Cout][Cin].
 size_t tatt_conv_skinny_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW) {
+  if (c4_direct_ok(Cin, Cout, KH, KW, 4, nullptr)) return (size_t)KH * KW * Cout * Cin + 64;  // direct kernel: packed weights only
   return (size_t)KH * KW * Cout * ((size_t)B * H * W + Cin) + 64;
 }
 
@@ -1114,6 +1247,15 @@ int tatt_conv_skinny_fwd(const float* X, const float* Wt, const float* bias, flo
   const int T = KH * KW;
   const long P = (long)B * H * W;
   TATT_CHECK_ARG(P < (1L << 31), "tatt_conv_skinny_fwd: too many pixels");
+  if (c4_direct_ok(Cin, Cout, KH, KW, ldx, X)) {  // 9x9, four output channels: direct convolution, no planar intermediate
+    hipLaunchKernelGGL(conv_c4_pack_w, dim3(cdiv((long)T * Cin * 4, 256)), dim3(256), 0, st, Wt, workspace, Cin, T, w_sn, w_sci, w_base, w_stap);
+    TATT_LAUNCH_CHECK("conv_c4_pack_w");
+    const int tiles_x = cdiv(W, C4_TW), tiles_y = cdiv(H, C4_TH);
+    hipLaunchKernelGGL(conv_c4_direct, dim3(tiles_x * tiles_y * B), dim3(256), 0, st, X, ldx, workspace, bias, Y, ldy, H, W, Cin, tiles_x,
+                       tiles_y, accumulate);
+    TATT_LAUNCH_CHECK("conv_c4_direct");
+    return TATT_OK;
+  }
   float* Wr = workspace;
   float* Z = workspace + (((size_t)T * Cout * Cin + 63) / 64) * 64;
   hipLaunchKernelGGL(skinny_repack_w, dim3(cdiv((long)T * Cout * Cin, 256)), dim3(256), 0, st, Wt, Wr, Cin, Cout, T, w_sn, w_sci, w_base,
@@ -1190,8 +1332,7 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
     if (int rc = launch<OP_ROWCONTIG, OP_IM2COL_N>(a, 1, st)) return rc;
   }
   long tot = (long)a.M * a.N;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, workspace, tot, splitk, dW, (const float*)nullptr,
-                     a.M, a.N, (long)a.N, accumulate, 0, perm, perm_c, T, 0L);
+  launch_splitk_reduce(st, 1, workspace, tot, splitk, dW, (const float*)nullptr, a.M, a.N, (long)a.N, accumulate, 0, perm, perm_c, T, 0L);
   TATT_LAUNCH_CHECK("conv_wgrad_reduce");
   return TATT_OK;
 }

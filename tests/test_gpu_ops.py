@@ -166,7 +166,7 @@ def test_conv3x3_wgrad_borders_and_slices(B, H, W, sk):
     close(dW, w.grad, what="overwrite")
 
 
-@pytest.mark.parametrize("B,H,W,Cbig,Csmall,k", [(2, 32, 128, 64, 4, 9), (3, 16, 64, 64, 4, 9), (2, 8, 8, 32, 8, 3), (1, 5, 7, 64, 16, 3)])
+@pytest.mark.parametrize("B,H,W,Cbig,Csmall,k", [(2, 32, 128, 64, 4, 9), (3, 16, 64, 64, 4, 9), (2, 7, 70, 32, 4, 9), (1, 3, 5, 16, 4, 9), (2, 8, 8, 32, 8, 3), (1, 5, 7, 64, 16, 3)])
 def test_conv_skinny_fwd_and_dgrad(B, H, W, Cbig, Csmall, k):
     """Skinny-Cout path: forward Cbig->Csmall, and the dgrad of a Csmall->Cbig conv (model/tsrn.py:625, :598)."""
     T = k * k
