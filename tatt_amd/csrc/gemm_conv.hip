@@ -758,6 +758,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   } else if (perm == 3) {  // tiny-Cout wgrad, roles swapped: m = ci_f, n = (flipped tap, co_f); Cin here = Cout_f
     int tapf = n / Cin, co = n - tapf * Cin;
     o = ((long)co * M + m) * T + (T - 1 - tapf);
+  } else if (perm == 4) {  // tiny-Cout wgrad with (flipped tap, co_f) on M and ci_f on N; Cin here = Cout_f
+    int tapf = m / Cin, co = m - tapf * Cin;
+    o = ((long)co * N + n) * T + (T - 1 - tapf);
   } else {
     o = (long)m * ldc + n;
   }
@@ -1307,15 +1310,28 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
     // tiny Cout (the 9x9 64->4 output conv): swap the roles of X and dY so that the wide tensor sits on the M side and
     // the im2col runs over the 4-channel one:  D[ci][(tap',co)] = sum_q X[q][ci] * dY[q+shift(tap')][co]
     //                                          = dW[co][ci][T-1-tap']   (undone by perm 3 in the reduce kernel)
-    a.A = X; a.B = dY;
-    a.M = Cin; a.N = T * Cout;
-    a.sam = 1; a.sak = ldx;
-    a.ldc = a.N;
-    a.sCz = (long)a.M * a.N;
+    // Which tensor goes on the 128-wide M side: with X there (M = Cin) a 64-channel conv fills half of every tile; with the
+    // im2col of dY there (M = T*Cout = 324 for the 9x9 output conv: 3 tiles, 16 % padding) and X on N the tiles are full.
     a.g = ConvGeom{H, W, Cout, KH, KW, KH / 2, KW / 2, (int)lddy};
-    perm = 3;
     perm_c = Cout;
-    if (int rc = launch<OP_ROWCONTIG, OP_IM2COL_N>(a, 1, st)) return rc;
+    if (Cin <= 64 && Cin % 4 == 0) {
+      a.A = dY; a.B = X;
+      a.M = T * Cout; a.N = Cin;
+      a.sam = 0; a.sak = 0;
+      a.sbn = 1; a.sbk = ldx;
+      a.ldc = a.N;
+      a.sCz = (long)a.M * a.N;
+      perm = 4;
+      if (int rc = launch<OP_IM2COL_M, OP_ROWCONTIG>(a, 1, st)) return rc;
+    } else {
+      a.A = X; a.B = dY;
+      a.M = Cin; a.N = T * Cout;
+      a.sam = 1; a.sak = ldx;
+      a.ldc = a.N;
+      a.sCz = (long)a.M * a.N;
+      perm = 3;
+      if (int rc = launch<OP_ROWCONTIG, OP_IM2COL_N>(a, 1, st)) return rc;
+    }
   } else if (Cout <= 64 && lddy % 4 == 0 && (((uintptr_t)dY) & 15) == 0) {
     // Cout <= 64 fits ONE 64-wide N tile: put (tap,ci) on the 128-wide M side so that no MFMA rows are padding
     // (with Cout on M a 64-channel conv would fill only half of every 128-row tile).

@@ -306,7 +306,9 @@ class Engine:
 
     def conv_wgrad(self, x, dy, dW, db, B, H, Wd, Cin, Cout, k, fp32=False):
         T = k * k
-        if Cout <= 16:                                         # roles swapped: M = Cin, N = T*Cout (see tatt_conv_wgrad)
+        if Cout <= 16 and Cin <= 64:                           # M = T*Cout (im2col of dY), N = Cin (see tatt_conv_wgrad)
+            tiles = -(-(T * Cout) // 128)
+        elif Cout <= 16:                                       # roles swapped: M = Cin, N = T*Cout
             tiles = -(-Cin // 128) * -(-(T * Cout) // 64)
         elif Cout <= 64:                                       # M = T*Cin, N = Cout
             tiles = -(-(T * Cin) // 128)
