@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void gru_unfold_grad_k(UnfoldArgs u) {
     const float* df = u.dWf + (long)j * Cin;   // wave-uniform row: scalar loads
     const float* wc = u.WcT + m;                // consecutive lanes read consecutive floats
     float s0 = u.dbf[j] * u.bc[m], s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int c = 0; c < Cin; c += 4) {          // four independent chains: the loads of a trip are in flight together
+#pragma unroll 8
+    for (int c = 0; c < Cin; c += 4) {          // four independent chains, eight trips unrolled: 64 loads in flight per thread
       s0 += df[c] * wc[(long)c * 64];
       s1 += df[c + 1] * wc[(long)(c + 1) * 64];
       s2 += df[c + 2] * wc[(long)(c + 2) * 64];
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256) void gru_unfold_grad_k(UnfoldArgs u) {
     for (int d = 0; d < 2; ++d) {
       const float* wi = u.Wih[d] + m;
       const float* df = u.dWf + (long)d * 96 * Cin + c;
+#pragma unroll 8
       for (int j = 0; j < 96; j += 4) {
         s0 += wi[j * 64] * df[(long)j * Cin];
         s1 += wi[(j + 1) * 64] * df[(long)(j + 1) * Cin];
