@@ -865,15 +865,19 @@ __global__ __launch_bounds__(256) void skinny_gather(const float* __restrict__ Z
 // With Cout = 4 every input value feeds only four multiply-adds per tap: on the matrix core 15/16 of a 64-wide tile would be padding,
 // and the planar-GEMM detour above (Z[(tap,co)][pixel], then a shifted gather) moves 324 floats per pixel through memory (340 MB at
 // B = 64).  fp32 FMA on the vector ALU has the same peak as fp32 MFMA on this chip, so the convolution runs there directly:
-//   * a workgroup owns a 4 x 64 pixel tile of one image; its four waves split the input channels (wave w takes channel quad w of
-//     every 16-channel chunk) and are summed through LDS at the end;
-//   * per chunk the tile + halo (12 x 72 pixels x 16 channels) is staged in LDS as [quad][row][col] float4, one pad slot per four
+//   * a workgroup owns an 8 x 64 pixel tile of one image; the input channels are walked in chunks of eight, wave (q, hh) takes
+//     channel quad q of the chunk for rows 4hh..4hh+3, and the two quads are summed through LDS at the end;
+//   * per chunk the tile + halo (16 x 72 pixels x 8 channels) is staged in LDS as [quad][row][col] float4, one pad slot per four
 //     columns so that the 16 lanes of a ds_read_b128 pass (four columns apart) hit distinct banks;
 //   * a thread computes 4 consecutive pixels x 4 output channels: per tap row it reads its 12-column window once (12 float4) and
-//     reuses it for the nine horizontal taps from registers -- 576 FMAs per 12 LDS reads;
-//   * the weights are wave-uniform: packed as [quad][tap][ci][co] they arrive by scalar loads and enter v_fma as SGPR operands.
-constexpr int C4_KS = 9, C4_HALO = 4, C4_TH = 4, C4_TW = 64, C4_PX = 4;
+//     reuses it for the nine horizontal taps from registers -- 576 FMAs per 12 window reads;
+//   * the weights, packed as [quad][tap][ci][co], are wave-uniform: staged per chunk in LDS and read as broadcasts.  (As scalar
+//     loads -- SGPR operands of v_pk_fma -- they cost more than the FMAs: the 83 KB overflow the scalar cache, scalar loads return
+//     out of order, so every s_load_dwordx16 was waited for with lgkmcnt(0) at L2 latency: 183 us instead of ~70 us of FMA work.)
+constexpr int C4_KS = 9, C4_HALO = 4, C4_TH = 8, C4_TW = 64, C4_PX = 4, C4_Q = 2;  // C4_Q channel quads (8 channels) per LDS chunk
 constexpr int C4_RW = C4_TW + 2 * C4_HALO, C4_RWP = C4_RW + C4_RW / 4, C4_RH = C4_TH + 2 * C4_HALO;
+constexpr int C4_TILE4 = C4_Q * C4_RH * C4_RWP;   // float4 slots of the staged input tile
+constexpr int C4_W4 = C4_Q * C4_KS * C4_KS * 4;   // float4 slots of the chunk's weights
 
 __global__ void conv_c4_pack_w(const float* __restrict__ Wt, float* __restrict__ Wp, int Cin, int T, long w_sn, long w_sci, long w_base,
                                long w_stap) {
@@ -886,82 +890,89 @@ __global__ void conv_c4_pack_w(const float* __restrict__ Wt, float* __restrict__
 __global__ __launch_bounds__(256, 2) void conv_c4_direct(const float* __restrict__ X, long ldx, const float* __restrict__ Wp,
                                                          const float* __restrict__ bias, float* __restrict__ Y, long ldy, int H, int W,
                                                          int Cin, int tiles_x, int tiles_y, int accumulate) {
-  __shared__ float4 tile[4 * C4_RH * C4_RWP];  // 69,120 bytes: two workgroups per CU
+  __shared__ float4 smem[C4_TILE4 + C4_W4];  // 46,080 + 10,368 bytes: two workgroups per CU
+  float4* tile = smem;
+  float4* wl = smem + C4_TILE4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = wave & 1, hh = wave >> 1;  // this wave: channel quad q of the chunk, rows hh*4 .. hh*4+3 of the tile
   int t = blockIdx.x;
   const int tx = t % tiles_x;
   t /= tiles_x;
   const int ty = t % tiles_y, b = t / tiles_y;
   const int y0 = ty * C4_TH, x0 = tx * C4_TW;
-  const int gy = lane >> 4, gx = (lane & 15) * C4_PX;  // this thread's pixels: row y0 + gy, columns x0 + gx .. + 3
+  const int gy = hh * 4 + (lane >> 4), gx = (lane & 15) * C4_PX;  // this thread's pixels: row y0 + gy, columns x0 + gx .. + 3
   const float* Xb = X + (long)b * H * W * ldx;
   float acc[C4_PX][4];
 #pragma unroll
   for (int p = 0; p < C4_PX; ++p)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
-  const int nchunk = Cin >> 4;
+  const int nchunk = Cin / (4 * C4_Q);
   for (int ch = 0; ch < nchunk; ++ch) {
-    __syncthreads();  // the previous chunk's window reads are done
-    for (int i = tid; i < C4_RH * C4_RW * 4; i += 256) {
-      const int q = i & 3, pos = i >> 2, r = pos / C4_RW, c = pos - r * C4_RW;
+    __syncthreads();  // the previous chunk's window / weight reads are done
+    for (int i = tid; i < C4_RH * C4_RW * C4_Q; i += 256) {
+      const int qq = i % C4_Q, pos = i / C4_Q, r = pos / C4_RW, c = pos - r * C4_RW;
       const int yy = y0 + r - C4_HALO, xx = x0 + c - C4_HALO;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-        v = *reinterpret_cast<const float4*>(Xb + ((long)yy * W + xx) * ldx + ch * 16 + q * 4);
-      tile[(q * C4_RH + r) * C4_RWP + c + (c >> 2)] = v;
+        v = *reinterpret_cast<const float4*>(Xb + ((long)yy * W + xx) * ldx + (ch * C4_Q + qq) * 4);
+      tile[(qq * C4_RH + r) * C4_RWP + c + (c >> 2)] = v;
     }
+    // the chunk's weights [quad][tap][ci][co]: read below with wave-uniform addresses (LDS broadcast).  Scalar loads would be the
+    // natural fit, but the 83 KB of weights overflow the scalar cache and every s_load then waits on L2 with lgkmcnt(0)
+    const float4* wg = reinterpret_cast<const float4*>(Wp) + (long)ch * C4_W4;
+    for (int i = tid; i < C4_W4; i += 256) wl[i] = wg[i];
     __syncthreads();
-    const float* __restrict__ wq = Wp + (long)((ch * 4 + wave) * C4_KS * C4_KS) * 16;
-    const float4* trow = tile + (wave * C4_RH + gy) * C4_RWP;
+    const float4* wq = wl + q * C4_KS * C4_KS * 4;
+    const float4* trow = tile + (q * C4_RH + gy) * C4_RWP;
 #pragma unroll 1
     for (int dy = 0; dy < C4_KS; ++dy) {
       float4 win[C4_PX + C4_KS - 1];
 #pragma unroll
       for (int j = 0; j < C4_PX + C4_KS - 1; ++j) win[j] = trow[dy * C4_RWP + (gx + j) + ((gx + j) >> 2)];
-      const float* __restrict__ wr = wq + dy * C4_KS * 16;
+      const float4* wr = wq + dy * C4_KS * 4;
 #pragma unroll
       for (int dx = 0; dx < C4_KS; ++dx) {
-        const float* __restrict__ w = wr + dx * 16;  // [ci4][co]: wave-uniform -> scalar loads, SGPR operands
+        const float4 w0 = wr[dx * 4], w1 = wr[dx * 4 + 1], w2 = wr[dx * 4 + 2], w3 = wr[dx * 4 + 3];  // rows ci = 0..3 of [ci][co]
 #pragma unroll
-        for (int p = 0; p < C4_PX; ++p)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            float a = acc[p][c];
-            a = fmaf(win[p + dx].x, w[c], a);
-            a = fmaf(win[p + dx].y, w[4 + c], a);
-            a = fmaf(win[p + dx].z, w[8 + c], a);
-            a = fmaf(win[p + dx].w, w[12 + c], a);
-            acc[p][c] = a;
-          }
+        for (int p = 0; p < C4_PX; ++p) {
+          const float4 xv = win[p + dx];
+          acc[p][0] = fmaf(xv.w, w3.x, fmaf(xv.z, w2.x, fmaf(xv.y, w1.x, fmaf(xv.x, w0.x, acc[p][0]))));
+          acc[p][1] = fmaf(xv.w, w3.y, fmaf(xv.z, w2.y, fmaf(xv.y, w1.y, fmaf(xv.x, w0.y, acc[p][1]))));
+          acc[p][2] = fmaf(xv.w, w3.z, fmaf(xv.z, w2.z, fmaf(xv.y, w1.z, fmaf(xv.x, w0.z, acc[p][2]))));
+          acc[p][3] = fmaf(xv.w, w3.w, fmaf(xv.z, w2.w, fmaf(xv.y, w1.w, fmaf(xv.x, w0.w, acc[p][3]))));
+        }
       }
     }
   }
-  // sum the four waves' channel partitions: [wave][pixel of the tile][co]
+  // sum the channel partitions of the two quad waves: [quad][pixel of the tile][co]
   __syncthreads();
-  float4* red = tile;
+  float4* red = smem;
+  const int pix0 = gy * C4_TW + gx;
 #pragma unroll
-  for (int p = 0; p < C4_PX; ++p) red[(wave * 256) + lane * C4_PX + p] = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+  for (int p = 0; p < C4_PX; ++p) red[q * (C4_TH * C4_TW) + pix0 + p] = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
   __syncthreads();
-  // thread tid finishes pixel tid of the tile (pixel index = lane_of_owner * 4 + p = (row * 16 + colgroup) * 4 + p = row * 64 + col)
-  const int py = tid >> 6, px = tid & 63;
-  const int yy = y0 + py, xx = x0 + px;
-  if (yy >= H || xx >= W) return;
-  float4 s = red[tid];
 #pragma unroll
-  for (int w2 = 1; w2 < 4; ++w2) {
-    const float4 v = red[w2 * 256 + tid];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  for (int k = 0; k < C4_TH * C4_TW / 256; ++k) {
+    const int pix = tid + 256 * k, py = pix / C4_TW, px = pix - py * C4_TW;
+    const int yy = y0 + py, xx = x0 + px;
+    if (yy >= H || xx >= W) continue;
+    float4 s = red[pix];
+#pragma unroll
+    for (int w2 = 1; w2 < C4_Q; ++w2) {
+      const float4 v = red[w2 * (C4_TH * C4_TW) + pix];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) { s.x += bias[0]; s.y += bias[1]; s.z += bias[2]; s.w += bias[3]; }
+    float* dst = Y + ((long)(b * H + yy) * W + xx) * ldy;
+    if (accumulate) { s.x += dst[0]; s.y += dst[1]; s.z += dst[2]; s.w += dst[3]; }
+    dst[0] = s.x; dst[1] = s.y; dst[2] = s.z; dst[3] = s.w;
   }
-  if (bias) { s.x += bias[0]; s.y += bias[1]; s.z += bias[2]; s.w += bias[3]; }
-  float* dst = Y + ((long)(b * H + yy) * W + xx) * ldy;
-  if (accumulate) { s.x += dst[0]; s.y += dst[1]; s.z += dst[2]; s.w += dst[3]; }
-  dst[0] = s.x; dst[1] = s.y; dst[2] = s.z; dst[3] = s.w;
 }
 
 inline bool c4_direct_ok(int Cin, int Cout, int KH, int KW, long ldx, const void* X) {
-  return Cout == 4 && KH == C4_KS && KW == C4_KS && Cin % 16 == 0 && ldx % 4 == 0 && (((uintptr_t)X) & 15) == 0;
+  return Cout == 4 && KH == C4_KS && KW == C4_KS && Cin % (4 * C4_Q) == 0 && ldx % 4 == 0 && (((uintptr_t)X) & 15) == 0;
 }
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
