@@ -140,7 +140,8 @@ int tatt_rpe_scatter_dx(const float* dx, float* dinit, int accumulate, hipStream
 
 /* ---- attention core, 4 heads x 16, 26 keys (nn.MultiheadAttention at model/transformer_v2.py:476,:819) ---- */
 int tatt_attn_fwd(const float* Q, const float* Kp, const float* Vp, float* ctx, float* pw, int B, int Lq, int nkeys, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t stream);
-int tatt_attn_bwd(const float* Q, const float* Kp, const float* Vp, const float* dctx, float* dQ, float* dK, float* dV, int B, int Lq, int nkeys, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, int accumulate_kv, hipStream_t stream);
+size_t tatt_attn_bwd_workspace(int B, int Lq);
+int tatt_attn_bwd(const float* Q, const float* Kp, const float* Vp, const float* dctx, float* dQ, float* dK, float* dV, int B, int Lq, int nkeys, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, int accumulate_kv, float* workspace, hipStream_t stream);
 int tatt_attn_avg(const float* pw, float* out, int B, int Lq, hipStream_t stream);
 
 /* ---- element-wise / layout (model/tsrn.py:599 PReLU, :1042-1043 PixelShuffle+mish, :683 sigmoid, :208, :212;

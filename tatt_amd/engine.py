@@ -501,7 +501,7 @@ class Engine:
         dc = self.new(Rq, 64)
         self.linear_dx(da, P[pre + "out_proj.weight"], dc, Rq, 64, 64)
         dQ, dK, dV = self.new(Rq, 64), self.new(Rk, 64), self.new(Rk, 64)
-        self.L.attn_bwd(Q, K, V, dc, dQ, dK, dV, B, Lq, 26, *cfg, 0)
+        self.L.attn_bwd(Q, K, V, dc, dQ, dK, dV, B, Lq, 26, *cfg, 0, self.new(self.L.attn_bwd_workspace(B, Lq)))
         trip = [(dQ, q_in, Rq, dq_in, acc_q), (dK, k_in, Rk, dk_in, acc_k), (dV, v_in, Rk, dv_in, acc_v)]
         self.linear_dwb_group([(d, x, dW[64 * i:], db[64 * i:], R, 64, 64, None, None, None) for i, (d, x, R, _, _) in enumerate(trip)])
         for i, (d, x, R, dx, acc) in enumerate(trip):

@@ -350,7 +350,7 @@ def test_rpe_fused_steps_vs_torch_gru():
         close(dwhh, getattr(gru, "weight_hh_l0" + sx).grad, what="dW_hh" + sx)
 
 
-@pytest.mark.parametrize("Lq,p", [(1024, 0.0), (26, 0.0), (1024, 0.1), (100, 0.1)])
+@pytest.mark.parametrize("Lq,p", [(1024, 0.0), (26, 0.0), (1024, 0.1), (100, 0.1), (300, 0.1)])
 def test_attention_fwd_bwd(Lq, p):
     B = 3
     Q, K_, V = [rnd(B * n, 64, seed=s).double().requires_grad_(True) for n, s in ((Lq, 1), (26, 2), (26, 3))]
@@ -375,7 +375,10 @@ def test_attention_fwd_bwd(Lq, p):
     L().attn_avg(pw, avg, B, Lq)
     close(avg, att.mean(1), what="attn avg")
     dQ, dK, dV = torch.empty(B * Lq, 64, device="cuda"), torch.empty(B * 26, 64, device="cuda"), torch.empty(B * 26, 64, device="cuda")
-    L().attn_bwd(Qd, Kd, Vd, cu(dctx), dQ, dK, dV, B, Lq, 26, *cfg, 0)
+    L().attn_bwd(Qd, Kd, Vd, cu(dctx), dQ, dK, dV, B, Lq, 26, *cfg, 0, ws(L().attn_bwd_workspace(B, Lq)))
+    dK2 = dK.clone()
+    L().attn_bwd(Qd, Kd, Vd, cu(dctx), dQ, dK2, dV.clone(), B, Lq, 26, *cfg, 1, ws(L().attn_bwd_workspace(B, Lq)))   # accumulate_kv
+    close(dK2, 2 * K_.grad, 5e-5, "dK accumulated")
     close(dQ, Q.grad, 5e-5, "dQ")
     close(dK, K_.grad, 5e-5, "dK")
     close(dV, V.grad, 5e-5, "dV")
