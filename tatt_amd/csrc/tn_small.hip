@@ -13,11 +13,14 @@ namespace {
 constexpr int TN_WAVES = 8, TN_MAXBLK = 256;
 constexpr int OOB = (int)0x80000000;  // buffer offset beyond num_records: the load returns 0
 
-template <int MT, int NT, bool SKIP>
+template <int MT, int NT>
 __device__ __forceinline__ void tn_small_body(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx, int M, int N,
                                               int R, int rows_per_blk, float* __restrict__ slabs, int blk, float* red) {
   constexpr int SLOT = MT * 32 * NT * 32 + MT * 32;  // one wave's partial: the MxN tile + the bias column sums
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform by construction; said so to the compiler: a VGPR-derived soffset wraps every buffer load in a readfirstlane
+  // waterfall loop (a basic block per load: nothing is batched or overlapped with the MFMAs)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int rb = blk * rows_per_blk, re = min(R, rb + rows_per_blk);
   const int rows_per_wave = ((rows_per_blk + 2 * TN_WAVES - 1) / (2 * TN_WAVES)) * 2;  // even
@@ -41,29 +44,30 @@ __device__ __forceinline__ void tn_small_body(const float* __restrict__ dY, long
 
   // Two register sets of U k-pairs each: the loads of the next set are issued before the MFMAs of the current one, so the
   // HBM latency and the matrix work (0.8 GFLOP for a [96,64] output, as long as the 42 MB stream itself) overlap inside a
-  // wave instead of adding up.  Straight-line, two sets per trip, rows past r1 predicated to zero.
+  // wave instead of adding up.  Straight-line, two sets per trip.  (A ring of four sets, loads three sets ahead, measured no
+  // faster: the kernel is not latency-bound once the loop is branch-free.)
   constexpr int U = 4;
   float av0[U][MT], bv0[U][NT], av1[U][MT], bv1[U][NT];
-  // Branch-free predication (a branch per load serialises them and forces vmcnt(0) before the first MFMA): raw buffer loads
-  // whose per-lane offset is swapped for an out-of-range one when the row or column is off -- the descriptor returns 0.
-  // Per-lane offsets are constants (column + lane half's row), the row position is the wave-uniform soffset.
-  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, OOB, 0x00020000);
+  // Branch-free predication: raw buffer loads whose descriptor ends at this wave's last row (num_records = r1 rows), the whole
+  // offset in the VGPR operand -- rows past r1 and columns past M / N (offset pushed beyond 2 GiB) come back as 0 with no
+  // compare, select or branch in the loop.  (The scalar offset operand is not range-checked, hence the VALU add per load.)
+  const int sy = (int)lddy * 4, sx = (int)ldx * 4;
+  const int r1u = __builtin_amdgcn_readfirstlane(r1 > 0 ? r1 : 0);
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, r1u * sy, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, r1u * sx, 0x00020000);
   int cy[MT], cx[NT];
 #pragma unroll
   for (int a = 0; a < MT; ++a) cy[a] = mok[a] ? (int)((lh * lddy + a * 32 + li) * 4) : OOB;
 #pragma unroll
   for (int b = 0; b < NT; ++b) cx[b] = nok[b] ? (int)((lh * ldx + b * 32 + li) * 4) : OOB;
-  const int sy = (int)lddy * 4, sx = (int)ldx * 4;
   auto load = [&](int r, float (&av)[U][MT], float (&bv)[U][NT]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int rw = r + 2 * u;
-      const bool rok = rw + lh < r1;
 #pragma unroll
-      for (int a = 0; a < MT; ++a) av[u][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rY, rok ? cy[a] : OOB, rw * sy, 0));
+      for (int a = 0; a < MT; ++a) av[u][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rY, cy[a] + rw * sy, 0, 0));
 #pragma unroll
-      for (int b = 0; b < NT; ++b) bv[u][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, rok ? cx[b] : OOB, rw * sx, 0));
+      for (int b = 0; b < NT; ++b) bv[u][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, cx[b] + rw * sx, 0, 0));
     }
   };
   auto mma = [&](const float (&av)[U][MT], const float (&bv)[U][NT]) {
@@ -71,11 +75,9 @@ __device__ __forceinline__ void tn_small_body(const float* __restrict__ dY, long
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int a = 0; a < MT; ++a) {
-        if (SKIP && a * 32 >= M) continue;  // block-uniform: a grouped launch runs smaller problems on the largest tile shape
         asum[a] += av[u][a];
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
-          if (!SKIP || b * 32 < N) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
       }
     }
   };
@@ -138,7 +140,7 @@ template <int MT, int NT>
 __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx,
                                                        int M, int N, int R, int rows_per_blk, float* __restrict__ slabs) {
   __shared__ float red[(TN_WAVES / 2) * (MT * 32 * NT * 32 + MT * 32)];
-  tn_small_body<MT, NT, false>(dY, lddy, X, ldx, M, N, R, rows_per_blk, slabs, blockIdx.x, red);
+  tn_small_body<MT, NT>(dY, lddy, X, ldx, M, N, R, rows_per_blk, slabs, blockIdx.x, red);
 }
 
 // Grouped form: up to TN_GROUP independent problems in one launch (blockIdx.y = problem), e.g. the four weight gradients of a
@@ -157,7 +159,20 @@ __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_group_kernel(TnGroup g
   __shared__ float red[(TN_WAVES / 2) * (3 * 32 * 2 * 32 + 3 * 32)];
   const int p = blockIdx.y;
   if ((int)blockIdx.x >= g.nblk[p]) return;
-  tn_small_body<3, 2, true>(g.dY[p], g.lddy[p], g.X[p], g.ldx[p], g.M[p], g.N[p], g.R[p], g.rpb[p], slabs + g.slab_off[p], blockIdx.x, red);
+  // block-uniform dispatch on the problem's tile shape (a per-MFMA "skip this tile" branch inside one shape split the loop into
+  // a basic block per MFMA: nothing overlapped)
+  const int mt = (g.M[p] + 31) >> 5, nt = (g.N[p] + 31) >> 5;
+#define TN_BODY(a, b) tn_small_body<a, b>(g.dY[p], g.lddy[p], g.X[p], g.ldx[p], g.M[p], g.N[p], g.R[p], g.rpb[p], slabs + g.slab_off[p], blockIdx.x, red)
+  if (nt == 1) {
+    if (mt == 1) TN_BODY(1, 1);
+    else if (mt == 2) TN_BODY(2, 1);
+    else TN_BODY(3, 1);
+  } else {
+    if (mt == 1) TN_BODY(1, 2);
+    else if (mt == 2) TN_BODY(2, 2);
+    else TN_BODY(3, 2);
+  }
+#undef TN_BODY
 }
 
 __global__ void tn_small_group_reduce(TnGroup g, const float* __restrict__ slabs) {
