@@ -150,10 +150,13 @@ __global__ void bn_stat_from_running(const float* __restrict__ rm, const float* 
   stat[C + c] = rsqrtf(rv[c] + eps);
 }
 
-// act: 0 none, 1 relu, 2 mish.  y = act(bn(x)) (+ res)
-__global__ void bn_apply_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ stat,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res,
-                                long ldr, float* __restrict__ y, long ldy, int R, int C, int act) {
+// act: 0 none, 1 relu, 2 mish.  y = act(bn(x)) (+ res).  ACT is a template parameter and the row tail is handled by clamping the
+// load row (stores predicated): with a run-time `act` and `if (r < R)` around every load the compiler emitted a basic block per
+// load with vmcnt(0) behind it -- the loads went out one at a time.
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ stat,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ res, long ldr, float* __restrict__ y, long ldy, int R, int C) {
   // thread = (float4 channel group, row lane); the channel group's scale/shift is folded once and kept in registers while the
   // thread walks BN_RPT rows (one thread per float4 re-read 16 parameters for every 16 bytes of payload)
   const int c4 = C >> 2, CT = c4 < 256 ? c4 : 256, RL = 256 / CT;
@@ -162,39 +165,37 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, long ldx, const flo
   const int rbase = blockIdx.x * (RL * BN_RPT) + rl;
   for (int cg = cl; cg < c4; cg += CT) {
     const int c = cg * 4;
-    float sc[4], sh[4], mu[4];
+    float mu[4], sc[4], ga[4], sh[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       mu[e] = stat[c + e];
       sc[e] = stat[C + c + e];
+      ga[e] = gamma[c + e];
       sh[e] = beta[c + e];
     }
-    float ga[4];
+    float4 v[BN_RPT], rr[BN_RPT];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ga[e] = gamma[c + e];
-    float4 v[BN_RPT];
+    for (int k = 0; k < BN_RPT; ++k) v[k] = *reinterpret_cast<const float4*>(x + (long)min(rbase + k * RL, R - 1) * ldx + c);
+    if (res) {
 #pragma unroll
-    for (int k = 0; k < BN_RPT; ++k) {
-      const int r = rbase + k * RL;
-      if (r < R) v[k] = *reinterpret_cast<const float4*>(x + (long)r * ldx + c);
+      for (int k = 0; k < BN_RPT; ++k) rr[k] = *reinterpret_cast<const float4*>(res + (long)min(rbase + k * RL, R - 1) * ldr + c);
+    } else {
+#pragma unroll
+      for (int k = 0; k < BN_RPT; ++k) rr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int k = 0; k < BN_RPT; ++k) {
       const int r = rbase + k * RL;
-      if (r >= R) break;
-      float in[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, out[4];
+      const float in[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, ad[4] = {rr[k].x, rr[k].y, rr[k].z, rr[k].w};
+      float out[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = (in[e] - mu[e]) * sc[e] * ga[e] + sh[e];
-        if (act == 1) t = fmaxf(t, 0.f);
-        else if (act == 2) t = mishf_(t);
-        out[e] = t;
+        if (ACT == 1) t = fmaxf(t, 0.f);
+        else if (ACT == 2) t = mishf_(t);
+        out[e] = t + ad[e];
       }
-      if (res) {
-        float4 rr = *reinterpret_cast<const float4*>(res + (long)r * ldr + c);
-        out[0] += rr.x; out[1] += rr.y; out[2] += rr.z; out[3] += rr.w;
-      }
-      *reinterpret_cast<float4*>(y + (long)r * ldy + c) = make_float4(out[0], out[1], out[2], out[3]);
+      if (r < R) *reinterpret_cast<float4*>(y + (long)r * ldy + c) = make_float4(out[0], out[1], out[2], out[3]);
     }
   }
 }
@@ -337,16 +338,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_final(const float* __restrict__ p
   }
 }
 
-// dx = gamma*invstd*(g - s1/R - xhat*s2/R) in training mode; eval mode (train=0): dx = gamma*invstd*g
-__global__ void bn_bwd_apply(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy,
-                             const float* __restrict__ stat, const float* __restrict__ gamma, const float* __restrict__ beta,
-                             const float* __restrict__ sums, float* __restrict__ dx, long lddx, int R, int C, int act, int train,
-                             int accumulate) {
+// dx = gamma*invstd*(g - s1/R - xhat*s2/R) in training mode; eval mode (train=0): dx = gamma*invstd*g.  Branch-free like bn_apply_kernel.
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy,
+                                                    const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const float* __restrict__ sums, float* __restrict__ dx,
+                                                    long lddx, int R, int C, int train, int accumulate) {
   const int c4 = C >> 2, CT = c4 < 256 ? c4 : 256, RL = 256 / CT;
   const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
   if (rl >= RL) return;
   const int rbase = blockIdx.x * (RL * BN_RPT) + rl;
-  const float invR = 1.f / (float)R;
+  const float invR = train ? 1.f / (float)R : 0.f;
   for (int cg = cl; cg < c4; cg += CT) {
     const int c = cg * 4;
     float mean[4], inv[4], ga[4], be[4], s1[4], s2[4];
@@ -355,33 +357,33 @@ __global__ void bn_bwd_apply(const float* __restrict__ x, long ldx, const float*
       mean[e] = stat[c + e]; inv[e] = stat[C + c + e]; ga[e] = gamma[c + e]; be[e] = beta[c + e];
       s1[e] = sums[c + e] * invR; s2[e] = sums[C + c + e] * invR;
     }
-    float4 xv[BN_RPT], gv[BN_RPT];
+    float4 xv[BN_RPT], gv[BN_RPT], pv[BN_RPT];
 #pragma unroll
     for (int k = 0; k < BN_RPT; ++k) {
-      const int r = rbase + k * RL;
-      if (r < R) {
-        xv[k] = *reinterpret_cast<const float4*>(x + (long)r * ldx + c);
-        gv[k] = *reinterpret_cast<const float4*>(dy + (long)r * lddy + c);
-      }
+      const long r = min(rbase + k * RL, R - 1);
+      xv[k] = *reinterpret_cast<const float4*>(x + r * ldx + c);
+      gv[k] = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+    }
+    if (accumulate) {
+#pragma unroll
+      for (int k = 0; k < BN_RPT; ++k) pv[k] = *reinterpret_cast<const float4*>(dx + (long)min(rbase + k * RL, R - 1) * lddx + c);
+    } else {
+#pragma unroll
+      for (int k = 0; k < BN_RPT; ++k) pv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int k = 0; k < BN_RPT; ++k) {
       const int r = rbase + k * RL;
-      if (r >= R) break;
-      float xi[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w}, gi[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w}, o[4];
+      const float xi[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w}, gi[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
+      const float pi[4] = {pv[k].x, pv[k].y, pv[k].z, pv[k].w};
+      float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float xh = (xi[e] - mean[e]) * inv[e];
-        float g = gi[e] * act_grad(xh * ga[e] + be[e], act);
-        float t = train ? (g - s1[e] - xh * s2[e]) : g;
-        o[e] = ga[e] * inv[e] * t;
+        const float xh = (xi[e] - mean[e]) * inv[e];
+        const float g = gi[e] * act_grad(xh * ga[e] + be[e], ACT);
+        o[e] = ga[e] * inv[e] * (g - s1[e] - xh * s2[e]) + pi[e];
       }
-      float* d = dx + (long)r * lddx + c;
-      if (accumulate) {
-        float4 p = *reinterpret_cast<const float4*>(d);
-        o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w;
-      }
-      *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+      if (r < R) *reinterpret_cast<float4*>(dx + (long)r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
 }
@@ -547,7 +549,12 @@ int tatt_bn_stat_from_running(const float* rm, const float* rv, int C, float eps
 int tatt_bn_apply(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr,
                   float* y, long ldy, int R, int C, int act, hipStream_t st) {
   TATT_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "tatt_bn_apply: C/ld must be multiples of 4");
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, stat, gamma, beta, res, ldr, y, ldy, R, C, act);
+  TATT_CHECK_ARG(act >= 0 && act <= 2 && R > 0, "tatt_bn_apply: act must be 0 (none), 1 (relu) or 2 (mish)");
+#define BN_APPLY(A) hipLaunchKernelGGL(bn_apply_kernel<A>, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, stat, gamma, beta, res, ldr, y, ldy, R, C)
+  if (act == 0) BN_APPLY(0);
+  else if (act == 1) BN_APPLY(1);
+  else BN_APPLY(2);
+#undef BN_APPLY
   TATT_LAUNCH_CHECK("bn_apply");
   return TATT_OK;
 }
@@ -564,8 +571,11 @@ int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const floa
   TATT_LAUNCH_CHECK("bn_bwd_reduce");
   hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 16)), dim3(nblk > 128 ? 1024 : 256), 0, st, workspace, nblk, C, sums, dgamma, dbeta, accumulate_params);
   TATT_LAUNCH_CHECK("bn_bwd_final");
-  hipLaunchKernelGGL(bn_bwd_apply, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, dy, lddy, stat, gamma, beta, sums, dx, lddx, R, C,
-                     act, train, accumulate_dx);
+#define BN_BWD_APPLY(A) hipLaunchKernelGGL(bn_bwd_apply<A>, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, dy, lddy, stat, gamma, beta, sums, dx, lddx, R, C, train, accumulate_dx)
+  if (act == 1) BN_BWD_APPLY(1);
+  else if (act == 2) BN_BWD_APPLY(2);
+  else BN_BWD_APPLY(0);
+#undef BN_BWD_APPLY
   TATT_LAUNCH_CHECK("bn_bwd_apply");
   return TATT_OK;
 }
@@ -591,8 +601,8 @@ int tatt_bn_bwd_from_partial(const float* x, long ldx, const float* g, long ldg,
                  "tatt_bn_bwd_from_partial: bad arguments");
   hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 16)), dim3(nblk > 128 ? 1024 : 256), 0, st, partial, nblk, C, sums, dgamma, dbeta, accumulate_params);
   TATT_LAUNCH_CHECK("bn_bwd_final");
-  hipLaunchKernelGGL(bn_bwd_apply, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, g, ldg, stat, gamma, beta, sums, dx, lddx, R, C,
-                     0, train, accumulate_dx);
+  hipLaunchKernelGGL(bn_bwd_apply<0>, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, g, ldg, stat, gamma, beta, sums, dx, lddx, R, C,
+                     train, accumulate_dx);
   TATT_LAUNCH_CHECK("bn_bwd_apply");
   return TATT_OK;
 }
