@@ -10,6 +10,7 @@
 // The k order inside an 8-wide k-group is permuted identically for A and B (lane half h takes k = 4h+e),
 // which lets k-contiguous operands be read as one b128 per 4 MFMAs.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -638,19 +639,23 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
       if (sok) {
         float xv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          xv[r] = ok[r] ? a.epi_x[(long)m * a.epi_ldx + n] : 0.f;
-        }
+        for (int r = 0; r < 16; ++r)  // row clamped, not predicated: sixteen independent loads, no branch around any of them
+          xv[r] = a.epi_x[(long)min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.M - 1) * a.epi_ldx + n];
         const float mean = a.epi_stat[n], inv = a.epi_stat[a.epi_C + n], ga = a.epi_gamma[n], be = a.epi_beta[n];
+        auto pass = [&](auto actc) {  // the activation is block-uniform: chosen once, outside the element loop
+          constexpr int ACT = decltype(actc)::value;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float xh = (xv[r] - mean) * inv;
-          const float g = ok[r] ? v[r] * epi_act_grad(xh * ga + be, a.epi_act) : 0.f;
-          s1 += g;
-          s2 += g * xh;
-          v[r] = g;
-        }
+          for (int r = 0; r < 16; ++r) {
+            const float xh = (xv[r] - mean) * inv;
+            const float g = ok[r] ? v[r] * epi_act_grad(xh * ga + be, ACT) : 0.f;
+            s1 += g;
+            s2 += g * xh;
+            v[r] = g;
+          }
+        };
+        if (a.epi_act == 2) pass(std::integral_constant<int, 2>{});
+        else if (a.epi_act == 1) pass(std::integral_constant<int, 1>{});
+        else pass(std::integral_constant<int, 0>{});
       }
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
@@ -673,12 +678,18 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
       ldc = a.ldc2;
       accum = a.accumulate2;
     }
+    if (accum) {  // all sixteen reads of the destination in flight together (a read-add-write per row waited on each in turn)
+      float prev[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) prev[r] = Cp[(long)min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.M - 1) * ldc + nn];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += prev[r];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (!ok[r]) continue;
       const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      float* dst = Cp + (long)m * ldc + nn;
-      *dst = accum ? v[r] + *dst : v[r];
+      Cp[(long)m * ldc + nn] = v[r];
     }
     return;
   } else {
@@ -693,17 +704,22 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
       ldc = a.ldc2;
       accum = a.accumulate2;
     }
+    float prev[16];
+    if (plain && accum) {  // all sixteen reads of the destination in flight together (a read-add-write per row waited on each in turn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) prev[r] = Cp[(long)min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.M - 1) * ldc + n];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) prev[r] = 0.f;
+    }
+    const bool relu = plain && a.relu;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m >= a.M) continue;
-      float v = acc[r] + bv;
-      float* dst = Cp + (long)m * ldc + n;
-      if (plain) {
-        if (accum) v += *dst;
-        if (a.relu) v = fmaxf(v, 0.f);
-      }
-      *dst = v;
+      float v = acc[r] + bv + prev[r];
+      if (relu) v = fmaxf(v, 0.f);
+      Cp[(long)m * ldc + n] = v;
     }
   }
 }
