@@ -72,8 +72,10 @@ size_t tatt_tn_small_workspace(int M, int N);
 int tatt_tn_small(const float* dY, long lddy, const float* X, long ldx, float* dW, long lddw, float* db, int M, int N, int R, float* workspace, hipStream_t stream);
 /* Grouped form: nprob <= 8 independent (dY, X, dW, db, M, N, R) problems in ONE launch pair, e.g. the weight gradients of a BiGRU
  * block (nn.GRU W_ih / W_hh of both directions + the 1x1 conv in front, model/tsrn.py GruBlock).  All array arguments are HOST
- * arrays of length nprob (db[p] may be NULL); workspace: tatt_tn_small_workspace(96, 64) floats. */
-int tatt_tn_small_group(int nprob, const float* const* dY, const long* lddy, const float* const* X, const long* ldx, float* const* dW, const long* lddw, float* const* db, const int* M, const int* N, const int* R, float* workspace, hipStream_t stream);
+ * arrays of length nprob (db[p] may be NULL); workspace: tatt_tn_small_workspace(96, 64) floats.  dY2 / lddy2 / msplit (all NULL, or
+ * arrays of length nprob with dY2[p] NULL where unused): columns m >= msplit[p] (a multiple of 32) of problem p's dY are read from
+ * dY2[p] at column m - msplit[p] -- the W_hh gradient takes its r / z gate columns from dgi and the n gate from tatt_gru32_bwd's dghn. */
+int tatt_tn_small_group(int nprob, const float* const* dY, const long* lddy, const float* const* X, const long* ldx, float* const* dW, const long* lddw, float* const* db, const int* M, const int* N, const int* R, const float* const* dY2, const long* lddy2, const int* msplit, float* workspace, hipStream_t stream);
 
 /* ---- NHWC implicit-GEMM convolution (stride 1, "same" zero padding), fwd / dgrad / wgrad -------------------
  * Replaces nn.Conv2d at model/tsrn.py:598 (9x9 4->64), :868,:876 (SRB 3x3), :614, :1034 (64->256), :625
@@ -123,7 +125,9 @@ int tatt_ln_bwd(const float* v, const float* dy, float dyscale, const float* gam
 
 /* ---- BiGRU(64 -> 2x32) recurrence of GruBlock (model/tsrn.py:1080,:1088), persistent half-wave per sequence - */
 int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* out, float* save, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride, hipStream_t stream);
-int tatt_gru32_bwd(const float* dout, const float* out, const float* save, const float* whh_f, const float* whh_b, float* dgi, float* dgh, float* hprev, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride, hipStream_t stream);
+/* dgi [P,192] = gradient of the input projections (dr, dz, dn per direction); dghn [P,64] (dir*32 + j) = dn * r, the one gate where
+ * the gradient of W_hh h + b_hh differs from dgi; hprev [P,64] = the state each step started from. */
+int tatt_gru32_bwd(const float* dout, const float* out, const float* save, const float* whh_f, const float* whh_b, float* dgi, float* dghn, float* hprev, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride, hipStream_t stream);
 
 /* ---- recurrent positional encoding GRU(1024 -> 2x512) gates (model/transformer_v2.py:177,:215-221) -------- */
 int tatt_rpe_gate_fwd(const float* gi, const float* gh, const float* bhh_f, const float* bhh_b, const float* hprev, float* hout, float* qp, int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t stream);

@@ -113,11 +113,12 @@ __global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, c
 }
 
 // BPTT. dout [P,64]; out [P,64] (forward output, gives h_prev); save [P,2,4,32];
-// writes dgi [P,192] (dr,dz,dn), dgh [P,192] (dr,dz,dn*r), hprev [P,64].
+// writes dgi [P,192] (dr,dz,dn), dghn [P,64] (dir*32 + j: dn*r, the only gate where the gradient of gh differs from that of gi --
+// the W_hh gradient reads its r / z columns from dgi), hprev [P,64].
 __global__ __launch_bounds__(256) void gru32_bwd(const float* __restrict__ dout, const float* __restrict__ out,
                                                  const float* __restrict__ save, const float* __restrict__ whh_f,
                                                  const float* __restrict__ whh_b, float* __restrict__ dgi,
-                                                 float* __restrict__ dgh, float* __restrict__ hprev_out, int nseq, SeqMap sm) {
+                                                 float* __restrict__ dghn, float* __restrict__ hprev_out, int nseq, SeqMap sm) {
   __shared__ __attribute__((aligned(16))) float gbuf[8][3 * HID];
   const int tid = threadIdx.x, j = tid & 31, slot = tid >> 5;
   int wi = blockIdx.x * 8 + slot;
@@ -170,9 +171,8 @@ __global__ __launch_bounds__(256) void gru32_bwd(const float* __restrict__ dout,
     gbuf[slot][2 * HID + j] = dgn;
     if (active) {
       float* gi_o = dgi + pix * 192 + dir * 96;
-      float* gh_o = dgh + pix * 192 + dir * 96;
       gi_o[j] = dr; gi_o[HID + j] = dz; gi_o[2 * HID + j] = dn;
-      gh_o[j] = dr; gh_o[HID + j] = dz; gh_o[2 * HID + j] = dgn;
+      dghn[pix * 64 + dir * HID + j] = dgn;
       hprev_out[pix * 64 + dir * HID + j] = hp;
     }
     __builtin_amdgcn_wave_barrier();
@@ -502,11 +502,11 @@ int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* whh_b, cons
 }
 
 int tatt_gru32_bwd(const float* dout, const float* out, const float* save, const float* whh_f, const float* whh_b, float* dgi,
-                   float* dgh, float* hprev, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride,
+                   float* dghn, float* hprev, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride,
                    hipStream_t st) {
   TATT_CHECK_ARG(nseq > 0 && T > 0 && inner > 0, "tatt_gru32_bwd: bad dims");
   SeqMap sm{inner, outer_stride, inner_stride, tstride, T};
-  hipLaunchKernelGGL(gru32_bwd, dim3(cdiv(nseq * 2, 8)), dim3(256), 0, st, dout, out, save, whh_f, whh_b, dgi, dgh, hprev, nseq, sm);
+  hipLaunchKernelGGL(gru32_bwd, dim3(cdiv(nseq * 2, 8)), dim3(256), 0, st, dout, out, save, whh_f, whh_b, dgi, dghn, hprev, nseq, sm);
   TATT_LAUNCH_CHECK("gru32_bwd");
   return TATT_OK;
 }

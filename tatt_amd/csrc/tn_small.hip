@@ -14,8 +14,9 @@ constexpr int TN_WAVES = 8, TN_MAXBLK = 256;
 constexpr int OOB = (int)0x80000000;  // buffer offset beyond num_records: the load returns 0
 
 template <int MT, int NT>
-__device__ __forceinline__ void tn_small_body(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx, int M, int N,
-                                              int R, int rows_per_blk, float* __restrict__ slabs, int blk, float* red) {
+__device__ __forceinline__ void tn_small_body(const float* __restrict__ dY, long lddy, const float* __restrict__ dY2, long lddy2, int msplit,
+                                              const float* __restrict__ X, long ldx, int M, int N, int R, int rows_per_blk,
+                                              float* __restrict__ slabs, int blk, float* red) {
   constexpr int SLOT = MT * 32 * NT * 32 + MT * 32;  // one wave's partial: the MxN tile + the bias column sums
   const int tid = threadIdx.x, lane = tid & 63;
   // wave-uniform by construction; said so to the compiler: a VGPR-derived soffset wraps every buffer load in a readfirstlane
@@ -51,13 +52,22 @@ __device__ __forceinline__ void tn_small_body(const float* __restrict__ dY, long
   // Branch-free predication: raw buffer loads whose descriptor ends at this wave's last row (num_records = r1 rows), the whole
   // offset in the VGPR operand -- rows past r1 and columns past M / N (offset pushed beyond 2 GiB) come back as 0 with no
   // compare, select or branch in the loop.  (The scalar offset operand is not range-checked, hence the VALU add per load.)
-  const int sy = (int)lddy * 4, sx = (int)ldx * 4;
+  // Columns m >= msplit of dY come from a second matrix (dY2, column m - msplit): the W_hh gradient of a GRU direction reads its
+  // r / z gate columns from dgi and only the n gate from its own [R,32] block.  Descriptor, row stride and lane offset are chosen
+  // per 32-column tile before the loop (block-uniform selects on scalar registers).
+  const int sx = (int)ldx * 4;
   const int r1u = __builtin_amdgcn_readfirstlane(r1 > 0 ? r1 : 0);
-  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, r1u * sy, 0x00020000);
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, r1u * sx, 0x00020000);
-  int cy[MT], cx[NT];
+  __amdgpu_buffer_rsrc_t rYa[MT];
+  int sya[MT], cy[MT], cx[NT];
 #pragma unroll
-  for (int a = 0; a < MT; ++a) cy[a] = mok[a] ? (int)((lh * lddy + a * 32 + li) * 4) : OOB;
+  for (int a = 0; a < MT; ++a) {
+    const bool second = a * 32 >= msplit;
+    const long ld = second ? lddy2 : lddy;
+    sya[a] = (int)ld * 4;
+    rYa[a] = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? dY2 : dY), 0, r1u * sya[a], 0x00020000);
+    cy[a] = mok[a] ? (int)((lh * ld + a * 32 - (second ? msplit : 0) + li) * 4) : OOB;
+  }
 #pragma unroll
   for (int b = 0; b < NT; ++b) cx[b] = nok[b] ? (int)((lh * ldx + b * 32 + li) * 4) : OOB;
   auto load = [&](int r, float (&av)[U][MT], float (&bv)[U][NT]) {
@@ -65,7 +75,7 @@ __device__ __forceinline__ void tn_small_body(const float* __restrict__ dY, long
     for (int u = 0; u < U; ++u) {
       const int rw = r + 2 * u;
 #pragma unroll
-      for (int a = 0; a < MT; ++a) av[u][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rY, cy[a] + rw * sy, 0, 0));
+      for (int a = 0; a < MT; ++a) av[u][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rYa[a], cy[a] + rw * sya[a], 0, 0));
 #pragma unroll
       for (int b = 0; b < NT; ++b) bv[u][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, cx[b] + rw * sx, 0, 0));
     }
@@ -140,7 +150,7 @@ template <int MT, int NT>
 __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx,
                                                        int M, int N, int R, int rows_per_blk, float* __restrict__ slabs) {
   __shared__ float red[(TN_WAVES / 2) * (MT * 32 * NT * 32 + MT * 32)];
-  tn_small_body<MT, NT>(dY, lddy, X, ldx, M, N, R, rows_per_blk, slabs, blockIdx.x, red);
+  tn_small_body<MT, NT>(dY, lddy, dY, lddy, 0x7fffffff, X, ldx, M, N, R, rows_per_blk, slabs, blockIdx.x, red);
 }
 
 // Grouped form: up to TN_GROUP independent problems in one launch (blockIdx.y = problem), e.g. the four weight gradients of a
@@ -148,6 +158,9 @@ __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_kernel(const float* __
 constexpr int TN_GROUP = 8;
 struct TnGroup {
   const float* dY[TN_GROUP];
+  const float* dY2[TN_GROUP];
+  long lddy2[TN_GROUP];
+  int msplit[TN_GROUP];
   const float* X[TN_GROUP];
   float* dW[TN_GROUP];
   float* db[TN_GROUP];
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_group_kernel(TnGroup g
   // block-uniform dispatch on the problem's tile shape (a per-MFMA "skip this tile" branch inside one shape split the loop into
   // a basic block per MFMA: nothing overlapped)
   const int mt = (g.M[p] + 31) >> 5, nt = (g.N[p] + 31) >> 5;
-#define TN_BODY(a, b) tn_small_body<a, b>(g.dY[p], g.lddy[p], g.X[p], g.ldx[p], g.M[p], g.N[p], g.R[p], g.rpb[p], slabs + g.slab_off[p], blockIdx.x, red)
+#define TN_BODY(a, b) tn_small_body<a, b>(g.dY[p], g.lddy[p], g.dY2[p], g.lddy2[p], g.msplit[p], g.X[p], g.ldx[p], g.M[p], g.N[p], g.R[p], g.rpb[p], slabs + g.slab_off[p], blockIdx.x, red)
   if (nt == 1) {
     if (mt == 1) TN_BODY(1, 1);
     else if (mt == 2) TN_BODY(2, 1);
@@ -239,9 +252,12 @@ int tatt_tn_small(const float* dY, long lddy, const float* X, long ldx, float* d
 }
 
 // Grouped form of tatt_tn_small: nprob <= 8 independent problems (host arrays of length nprob) in one launch pair.
-// workspace: tatt_tn_small_workspace(96, 64) floats cover any group.
+// workspace: tatt_tn_small_workspace(96, 64) floats cover any group.  dY2 / lddy2 / msplit (all three null, or arrays of length
+// nprob; dY2[p] null = none): columns m >= msplit[p] (a multiple of 32) of problem p's dY are read from dY2[p] at column m - msplit[p].
 int tatt_tn_small_group(int nprob, const float* const* dY, const long* lddy, const float* const* X, const long* ldx, float* const* dW,
-                        const long* lddw, float* const* db, const int* M, const int* N, const int* R, float* workspace, hipStream_t st) {
+                        const long* lddw, float* const* db, const int* M, const int* N, const int* R, const float* const* dY2,
+                        const long* lddy2, const int* msplit, float* workspace, hipStream_t st) {
+  TATT_CHECK_ARG((dY2 && lddy2 && msplit) || (!dY2 && !lddy2 && !msplit), "tatt_tn_small_group: dY2, lddy2 and msplit come together");
   TATT_CHECK_ARG(nprob > 0 && nprob <= TN_GROUP && dY && lddy && X && ldx && dW && lddw && db && M && N && R && workspace,
                  "tatt_tn_small_group: need 1..%d problems and non-null arrays", TN_GROUP);
   TnGroup g;
@@ -260,6 +276,12 @@ int tatt_tn_small_group(int nprob, const float* const* dY, const long* lddy, con
     const int rpb = ((R[p] + nblk - 1) / nblk + 15) / 16 * 16;
     nblk = (R[p] + rpb - 1) / rpb;
     g.dY[p] = dY[p]; g.X[p] = X[p]; g.dW[p] = dW[p]; g.db[p] = db[p];
+    g.dY2[p] = dY[p]; g.lddy2[p] = lddy[p]; g.msplit[p] = 0x7fffffff;
+    if (dY2 && dY2[p]) {
+      TATT_CHECK_ARG(msplit[p] > 0 && msplit[p] % 32 == 0 && msplit[p] < M[p] && lddy2[p] > 0 && ((long)R[p] + 1) * lddy2[p] * 4 < (1L << 31),
+                     "tatt_tn_small_group: problem %d: msplit must be a multiple of 32 inside (0, M), lddy2 > 0, dY2 under 2 GiB", p);
+      g.dY2[p] = dY2[p]; g.lddy2[p] = lddy2[p]; g.msplit[p] = msplit[p];
+    }
     g.lddy[p] = lddy[p]; g.ldx[p] = ldx[p]; g.lddw[p] = lddw[p];
     g.M[p] = M[p]; g.N[p] = N[p]; g.R[p] = R[p]; g.rpb[p] = rpb; g.nblk[p] = nblk;
     g.slab_off[p] = off;

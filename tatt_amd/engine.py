@@ -216,19 +216,24 @@ class Engine:
             self.colsum(dy, R, N, db, ld=lddy)
 
     def linear_dwb_group(self, probs):
-        """Several linear_dwb problems (dy, x, dW, db, R, N, K, lddy, ldx, lddw) of the small kind (N <= 96, K <= 64) in one
-        launch pair (tatt_tn_small_group): fewer, longer row ranges per workgroup and one slab reduction for the lot."""
+        """Several linear_dwb problems (dy, x, dW, db, R, N, K, lddy, ldx, lddw[, dy2, lddy2, nsplit]) of the small kind (N <= 96,
+        K <= 64) in one launch pair (tatt_tn_small_group): fewer, longer row ranges per workgroup and one slab reduction for the
+        lot.  dy2: columns >= nsplit of dy come from that second matrix."""
         assert all(p[5] <= 96 and p[6] <= 64 for p in probs)
         for i in range(0, len(probs), 8):
-            ch = probs[i:i + 8]
+            ch = [tuple(p) + (None, None, None) * (len(p) == 10) for p in probs[i:i + 8]]
             n = len(ch)
             VP, LG, IN = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+            two = any(p[10] is not None for p in ch)
             args = (n, VP(*[p[0].data_ptr() for p in ch]), LG(*[p[7] or p[5] for p in ch]),
                     VP(*[p[1].data_ptr() for p in ch]), LG(*[p[8] or p[6] for p in ch]),
                     VP(*[p[2].data_ptr() for p in ch]), LG(*[p[9] or p[6] for p in ch]),
                     VP(*[None if p[3] is None else p[3].data_ptr() for p in ch]),
-                    IN(*[p[5] for p in ch]), IN(*[p[6] for p in ch]), IN(*[p[4] for p in ch]))
-            self._wgrad(lambda ws, args=args: self.L.tn_small_group(*args, ws), [p[0] for p in ch], [p[1] for p in ch])
+                    IN(*[p[5] for p in ch]), IN(*[p[6] for p in ch]), IN(*[p[4] for p in ch]),
+                    VP(*[None if p[10] is None else p[10].data_ptr() for p in ch]) if two else None,
+                    LG(*[p[11] or 0 for p in ch]) if two else None, IN(*[p[12] or 0 for p in ch]) if two else None)
+            self._wgrad(lambda ws, args=args: self.L.tn_small_group(*args, ws), [p[0] for p in ch] + [p[10] for p in ch if p[10] is not None],
+                        [p[1] for p in ch])
 
     def colsum(self, x, R, C, out, ld=None):
         self._wgrad(lambda ws: self.L.colsum(x, ld or C, R, C, out, 1, ws), [x])
@@ -440,8 +445,8 @@ class Engine:
         also reduces (sum g, sum g xhat) over its rows and the partial sums are returned (part, nblk) for bn_bwd_part()."""
         P, R, L = self.P, B * H * W, self.L
         out, sv = ctx[key]
-        dgi, dgh, hprev = self.new(R, 192), self.new(R, 192), self.new(R, 64)
-        L.gru32_bwd(dout, out, sv, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], dgi, dgh, hprev,
+        dgi, dghn, hprev = self.new(R, 192), self.new(R, 64), self.new(R, 64)
+        L.gru32_bwd(dout, out, sv, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], dgi, dghn, hprev,
                     *self._seqmap(B, H, W, vertical))
         Wf, _, WcT = self._gru_fold()[pre]
         Cin = Wf.shape[1]
@@ -449,8 +454,9 @@ class Engine:
         dWf, dbf = tmp[:192 * Cin], tmp[192 * Cin:]
         wg = []                                               # all streaming weight gradients of the block: one grouped launch
         for d, sfx in enumerate(["", "_reverse"]):
-            gi_d, gh_d, hp_d = dgi.view(-1)[96 * d:], dgh.view(-1)[96 * d:], hprev.view(-1)[32 * d:]
-            wg.append((gh_d, hp_d, G[pre + "gru.weight_hh_l0" + sfx], G[pre + "gru.bias_hh_l0" + sfx], R, 96, 32, 192, 64, None))
+            gi_d, ghn_d, hp_d = dgi.view(-1)[96 * d:], dghn.view(-1)[32 * d:], hprev.view(-1)[32 * d:]
+            # dgh = (dr, dz | dn*r): the r / z columns are dgi's, only the n gate has a block of its own
+            wg.append((gi_d, hp_d, G[pre + "gru.weight_hh_l0" + sfx], G[pre + "gru.bias_hh_l0" + sfx], R, 96, 32, 192, 64, None, ghn_d, 64, 64))
             for s, (x, _, _) in enumerate(inputs):
                 wg.append((gi_d, x, dWf[96 * d * Cin + 64 * s:], dbf[96 * d:] if s == 0 else None, R, 96, 64, 192, None, Cin))
         self.linear_dwb_group(wg)                             # queued before the input gradients below may update a dx in place

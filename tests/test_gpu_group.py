@@ -26,6 +26,8 @@ def test_group_matches_fp64_and_single(R):
         (extra, 40, g_in, 64, 40, 64, R2, True),
         (hp, 64, extra, 40, 7, 33, R, True),
     ]
+    # second source for the columns >= msplit of problem 0 (the n gate of a GRU direction's W_hh gradient) and of problem 3
+    second = {0: (g_in.view(-1)[32:], 64, 64), 3: (hp, 64, 32)}
     ws = torch.empty(L.tn_small_workspace(96, 64), device="cuda")
     dWs = [torch.ones(M, N + 3, device="cuda") for (_, _, _, _, M, N, _, _) in probs]      # row stride lddw > N
     dbs = [torch.ones(M, device="cuda") if wb else None for (*_, M, _, _, wb) in probs]
@@ -34,14 +36,20 @@ def test_group_matches_fp64_and_single(R):
     L.tn_small_group(n, VP(*[p[0].data_ptr() for p in probs]), LG(*[p[1] for p in probs]), VP(*[p[2].data_ptr() for p in probs]),
                      LG(*[p[3] for p in probs]), VP(*[d.data_ptr() for d in dWs]), LG(*[d.shape[1] for d in dWs]),
                      VP(*[None if b is None else b.data_ptr() for b in dbs]), IN(*[p[4] for p in probs]), IN(*[p[5] for p in probs]),
-                     IN(*[p[6] for p in probs]), ws)
-    for (dy, lddy, x, ldx, M, N, Rp, wb), dW, db in zip(probs, dWs, dbs):
+                     IN(*[p[6] for p in probs]), VP(*[second[i][0].data_ptr() if i in second else None for i in range(n)]),
+                     LG(*[second[i][1] if i in second else 0 for i in range(n)]), IN(*[second[i][2] if i in second else 0 for i in range(n)]), ws)
+    for i, ((dy, lddy, x, ldx, M, N, Rp, wb), dW, db) in enumerate(zip(probs, dWs, dbs)):
         dyv = torch.as_strided(dy, (Rp, M), (lddy, 1)).cpu().double()
+        if i in second:
+            d2, ld2, ms = second[i]
+            dyv[:, ms:] = torch.as_strided(d2, (Rp, M - ms), (ld2, 1)).cpu().double()
         xv = torch.as_strided(x, (Rp, N), (ldx, 1)).cpu().double()
         assert rel_l2(dW[:, :N].cpu().double().numpy(), (1 + dyv.t() @ xv).numpy()) < 2e-5
         assert torch.equal(dW[:, N:].cpu(), torch.ones(M, 3))
         if wb:
             assert rel_l2(db.cpu().double().numpy(), (1 + dyv.sum(0)).numpy()) < 2e-5
+        if i in second:
+            continue
         one = torch.ones(M, N + 3, device="cuda")
         L.tn_small(dy, lddy, x, ldx, one, N + 3, None, M, N, Rp, ws)
         assert rel_l2(one[:, :N].cpu().double().numpy(), dW[:, :N].cpu().double().numpy()) < 5e-6

@@ -292,8 +292,11 @@ def test_gru32_fwd_bwd(vertical):
     out, sv = torch.empty(Rr, 64, device="cuda"), torch.empty(Rr, 2, 4, 32, device="cuda")
     L().gru32_fwd(gi, f32("weight_hh_l0"), f32("weight_hh_l0_reverse"), f32("bias_hh_l0"), f32("bias_hh_l0_reverse"), out, sv, *sm)
     close(out.view(B, H, W, 64), o, what="gru fwd")
-    dgi, dgh, hp = torch.empty(Rr, 192, device="cuda"), torch.empty(Rr, 192, device="cuda"), torch.empty(Rr, 64, device="cuda")
-    L().gru32_bwd(cu(dout.reshape(Rr, 64)), out, sv, f32("weight_hh_l0"), f32("weight_hh_l0_reverse"), dgi, dgh, hp, *sm)
+    dgi, dghn, hp = torch.empty(Rr, 192, device="cuda"), torch.empty(Rr, 64, device="cuda"), torch.empty(Rr, 64, device="cuda")
+    L().gru32_bwd(cu(dout.reshape(Rr, 64)), out, sv, f32("weight_hh_l0"), f32("weight_hh_l0_reverse"), dgi, dghn, hp, *sm)
+    dgh = dgi.clone()                                                        # dgh = dgi with the n gate replaced by dghn (= dn * r)
+    for d in range(2):
+        dgh[:, 96 * d + 64:96 * d + 96] = dghn[:, 32 * d:32 * d + 32]
     dx = torch.zeros(Rr, 64, device="cuda")
     for d, sfx in enumerate(("", "_reverse")):
         dW = torch.zeros(96, 32, device="cuda")

@@ -79,7 +79,7 @@ gi, out, sv = rnd(R, 192), rnd(R, 64), rnd(R, 2, 4, 32)
 whh, bhh = rnd(96, 32) * 0.2, rnd(96)
 t("gru32 fwd horizontal", lambda: L.gru32_fwd(gi, whh, whh, bhh, bhh, out, sv, B * 16, 64, 1, 64, 0, 1), 0, R * (768 + 256 + 1024))
 t("gru32 fwd vertical", lambda: L.gru32_fwd(gi, whh, whh, bhh, bhh, out, sv, B * 64, 16, 64, 1024, 1, 64), 0, R * (768 + 256 + 1024))
-dgi, dgh, hp = rnd(R, 192), rnd(R, 192), rnd(R, 64)
+dgi, dgh, hp = rnd(R, 192), rnd(R, 64), rnd(R, 64)
 t("gru32 bwd horizontal", lambda: L.gru32_bwd(x64, out, sv, whh, whh, dgi, dgh, hp, B * 16, 64, 1, 64, 0, 1), 0, R * 3000)
 t("gru32 bwd vertical", lambda: L.gru32_bwd(x64, out, sv, whh, whh, dgi, dgh, hp, B * 64, 16, 64, 1024, 1, 64), 0, R * 3000)
 dWs, dbs = rnd(64, 64), rnd(64)

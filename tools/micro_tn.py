@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tatt_amd.lib import lib
 L = lib()
 R = 65536
-dgi, dgh, hp = (torch.randn(R, 192, device="cuda"), torch.randn(R, 192, device="cuda"), torch.randn(R, 64, device="cuda"))
+dgi, dghn, hp = (torch.randn(R, 192, device="cuda"), torch.randn(R, 64, device="cuda"), torch.randn(R, 64, device="cuda"))
 x1, x2 = torch.randn(R, 64, device="cuda"), torch.randn(R, 64, device="cuda")
 ws = torch.empty(L.tn_small_workspace(96, 64), device="cuda")
 
@@ -19,14 +19,15 @@ def group(nin):
     dWhh, dbhh = torch.zeros(2, 96 * 32, device="cuda"), torch.zeros(2, 96, device="cuda")
     pr = []
     for d in range(2):
-        pr.append((dgh.view(-1)[96 * d:], hp.view(-1)[32 * d:], dWhh[d], dbhh[d], R, 96, 32, 192, 64, 32))
+        pr.append((dgi.view(-1)[96 * d:], hp.view(-1)[32 * d:], dWhh[d], dbhh[d], R, 96, 32, 192, 64, 32, dghn.view(-1)[32 * d:]))
         for s, x in enumerate([x1, x2][:nin]):
             pr.append((dgi.view(-1)[96 * d:], x, dWf[96 * d * Cin + 64 * s:], dbf[96 * d:] if s == 0 else None, R, 96, 64, 192, 64, Cin))
     n = len(pr)
     VP, LG, IN = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
     args = (n, VP(*[p[0].data_ptr() for p in pr]), LG(*[p[7] for p in pr]), VP(*[p[1].data_ptr() for p in pr]), LG(*[p[8] for p in pr]),
             VP(*[p[2].data_ptr() for p in pr]), LG(*[p[9] for p in pr]), VP(*[None if p[3] is None else p[3].data_ptr() for p in pr]),
-            IN(*[p[5] for p in pr]), IN(*[p[6] for p in pr]), IN(*[p[4] for p in pr]))
+            IN(*[p[5] for p in pr]), IN(*[p[6] for p in pr]), IN(*[p[4] for p in pr]),
+            VP(*[p[10].data_ptr() if len(p) > 10 else None for p in pr]), LG(*[64] * n), IN(*[64] * n))
     for _ in range(10):
         L.tn_small_group(*args, ws)
     torch.cuda.synchronize()
