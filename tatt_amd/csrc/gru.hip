@@ -51,10 +51,11 @@ __global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, c
   long pix = base + (long)(dir ? T - 1 : 0) * sm.tstride;
   const long pstep = dir ? -sm.tstride : sm.tstride;
   // The horizontal pass has one wave per SIMD, so nothing hides a global load but the chain itself: the input projections
-  // are fetched PF steps ahead, a chunk at a time (time index clamped instead of predicated: no branches around the loads).
-  constexpr int PF = 8;
+  // are fetched in sets of PF steps, two sets ahead of their use (time index clamped instead of predicated: no branches around
+  // the loads; see gru32_bwd for why one set ahead is not enough).
+  constexpr int PF = 4;
   const float* gcol = gi + dir * 96 + j;
-  float c_r[PF], c_z[PF], c_n[PF], q_r[PF], q_z[PF], q_n[PF];
+  float rA[PF], zA[PF], nA[PF], rB[PF], zB[PF], nB[PF], rC[PF], zC[PF], nC[PF];
   auto fetch = [&](int t0, float (&fr)[PF], float (&fz)[PF], float (&fn)[PF]) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -65,50 +66,52 @@ __global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, c
       fn[u] = q[2 * HID];
     }
   };
-  fetch(0, c_r, c_z, c_n);
-  for (int t0 = 0; t0 < T; t0 += PF) {
-    fetch(t0 + PF, q_r, q_z, q_n);
+  auto steps = [&](int t0, const float (&c_r)[PF], const float (&c_z)[PF], const float (&c_n)[PF]) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-    if (t0 + u >= T) break;
-    const float g_r = c_r[u], g_z = c_z[u], g_n = c_n[u];
-    __builtin_amdgcn_wave_barrier();
-    f32x2 ar2 = {br, 0.f}, az2 = {bz, 0.f}, an2 = {bn, 0.f};
+      if (t0 + u >= T) break;
+      const float g_r = c_r[u], g_z = c_z[u], g_n = c_n[u];
+      __builtin_amdgcn_wave_barrier();
+      f32x2 ar2 = {br, 0.f}, az2 = {bz, 0.f}, an2 = {bn, 0.f};
 #pragma unroll
-    for (int k4 = 0; k4 < HID / 4; ++k4) {
-      const float4 hv = *reinterpret_cast<const float4*>(&hbuf[slot][k4 * 4]);
-      const f32x2 h0 = {hv.x, hv.y}, h1 = {hv.z, hv.w};
-      ar2 = __builtin_elementwise_fma(wr[2 * k4], h0, ar2);
-      az2 = __builtin_elementwise_fma(wz[2 * k4], h0, az2);
-      an2 = __builtin_elementwise_fma(wn[2 * k4], h0, an2);
-      ar2 = __builtin_elementwise_fma(wr[2 * k4 + 1], h1, ar2);
-      az2 = __builtin_elementwise_fma(wz[2 * k4 + 1], h1, az2);
-      an2 = __builtin_elementwise_fma(wn[2 * k4 + 1], h1, an2);
-    }
-    const float ar = ar2.x + ar2.y, az = az2.x + az2.y, an = an2.x + an2.y;
-    float r = sigmoidf_(g_r + ar), z = sigmoidf_(g_z + az);
-    float n = tanhf_(g_n + r * an);
-    h = (1.f - z) * n + z * h;
-    __builtin_amdgcn_wave_barrier();
-    hbuf[slot][j] = h;
-    if (active) {
-      out[pix * 64 + dir * HID + j] = h;
-      if (save) {
-        float* sp = save + (pix * 2 + dir) * 4 * HID;
-        sp[j] = r;
-        sp[HID + j] = z;
-        sp[2 * HID + j] = n;
-        sp[3 * HID + j] = an;
+      for (int k4 = 0; k4 < HID / 4; ++k4) {
+        const float4 hv = *reinterpret_cast<const float4*>(&hbuf[slot][k4 * 4]);
+        const f32x2 h0 = {hv.x, hv.y}, h1 = {hv.z, hv.w};
+        ar2 = __builtin_elementwise_fma(wr[2 * k4], h0, ar2);
+        az2 = __builtin_elementwise_fma(wz[2 * k4], h0, az2);
+        an2 = __builtin_elementwise_fma(wn[2 * k4], h0, an2);
+        ar2 = __builtin_elementwise_fma(wr[2 * k4 + 1], h1, ar2);
+        az2 = __builtin_elementwise_fma(wz[2 * k4 + 1], h1, az2);
+        an2 = __builtin_elementwise_fma(wn[2 * k4 + 1], h1, an2);
       }
+      const float ar = ar2.x + ar2.y, az = az2.x + az2.y, an = an2.x + an2.y;
+      float r = sigmoidf_(g_r + ar), z = sigmoidf_(g_z + az);
+      float n = tanhf_(g_n + r * an);
+      h = (1.f - z) * n + z * h;
+      __builtin_amdgcn_wave_barrier();
+      hbuf[slot][j] = h;
+      if (active) {
+        out[pix * 64 + dir * HID + j] = h;
+        if (save) {
+          float* sp = save + (pix * 2 + dir) * 4 * HID;
+          sp[j] = r;
+          sp[HID + j] = z;
+          sp[2 * HID + j] = n;
+          sp[3 * HID + j] = an;
+        }
+      }
+      pix += pstep;
     }
-    pix += pstep;
-    }
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      c_r[u] = q_r[u];
-      c_z[u] = q_z[u];
-      c_n[u] = q_n[u];
-    }
+  };
+  fetch(0, rA, zA, nA);
+  fetch(PF, rB, zB, nB);
+  for (int t0 = 0; t0 < T; t0 += 3 * PF) {
+    fetch(t0 + 2 * PF, rC, zC, nC);
+    steps(t0, rA, zA, nA);
+    fetch(t0 + 3 * PF, rA, zA, nA);
+    steps(t0 + PF, rB, zB, nB);
+    fetch(t0 + 4 * PF, rB, zB, nB);
+    steps(t0 + 2 * PF, rC, zC, nC);
   }
 }
 
@@ -135,10 +138,13 @@ __global__ __launch_bounds__(256) void gru32_bwd(const float* __restrict__ dout,
   long pix = base + (long)(dir ? 0 : T - 1) * sm.tstride;
   const long pstep = dir ? sm.tstride : -sm.tstride;  // towards the forward-order predecessor
   float dh = 0.f;
-  // same scheme as the forward pass: the six per-step operands are fetched PF steps ahead, clamped rather than predicated
+  // The six per-step operands are fetched in sets of PF steps, TWO sets ahead of their use (time index clamped rather than
+  // predicated: no branches around the loads).  One set ahead was 4 steps = 0.8 us of cover, less than the memory latency behind
+  // the step's own seven stores (they share the counter the loads are waited on): the horizontal pass (one wave per SIMD,
+  // nothing else to hide it) stalled every trip, 1.1 us per step instead of 0.2.
   constexpr int PF = 4;
   const long pix0 = pix;
-  float c_s[PF][4], c_hp[PF], c_do[PF], q_s[PF][4], q_hp[PF], q_do[PF];
+  float sA[PF][4], hA[PF], dA[PF], sB[PF][4], hB[PF], dB[PF], sC[PF][4], hC[PF], dC[PF];
   auto fetch = [&](int t0, float (&fs)[PF][4], float (&fhp)[PF], float (&fdo)[PF]) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -151,48 +157,49 @@ __global__ __launch_bounds__(256) void gru32_bwd(const float* __restrict__ dout,
       fdo[u] = dout[pc * 64 + dir * HID + j];
     }
   };
-  fetch(0, c_s, c_hp, c_do);
-  for (int t0 = 0; t0 < T; t0 += PF) {
-    fetch(t0 + PF, q_s, q_hp, q_do);
+  auto steps = [&](int t0, const float (&c_s)[PF][4], const float (&c_hp)[PF], const float (&c_do)[PF]) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-    const int t = t0 + u;
-    if (t >= T) break;
-    const float r = c_s[u][0], z = c_s[u][1], n = c_s[u][2], ghn = c_s[u][3];
-    const float hp = (t + 1 < T) ? c_hp[u] : 0.f;
-    float d = dh + c_do[u];
-    float dn = d * (1.f - z) * (1.f - n * n);
-    float dz = d * (hp - n) * z * (1.f - z);
-    float dr = dn * ghn * r * (1.f - r);
-    float dgn = dn * r;
-    __builtin_amdgcn_wave_barrier();
-    gbuf[slot][j] = dr;
-    gbuf[slot][HID + j] = dz;
-    gbuf[slot][2 * HID + j] = dgn;
-    if (active) {
-      float* gi_o = dgi + pix * 192 + dir * 96;
-      gi_o[j] = dr; gi_o[HID + j] = dz; gi_o[2 * HID + j] = dn;
-      dghn[pix * 64 + dir * HID + j] = dgn;
-      hprev_out[pix * 64 + dir * HID + j] = hp;
-    }
-    __builtin_amdgcn_wave_barrier();
-    f32x2 a0 = {d * z, 0.f}, a1 = {0.f, 0.f};
+      const int t = t0 + u;
+      if (t >= T) break;
+      const float r = c_s[u][0], z = c_s[u][1], n = c_s[u][2], ghn = c_s[u][3];
+      const float hp = (t + 1 < T) ? c_hp[u] : 0.f;
+      float d = dh + c_do[u];
+      float dn = d * (1.f - z) * (1.f - n * n);
+      float dz = d * (hp - n) * z * (1.f - z);
+      float dr = dn * ghn * r * (1.f - r);
+      float dgn = dn * r;
+      __builtin_amdgcn_wave_barrier();
+      gbuf[slot][j] = dr;
+      gbuf[slot][HID + j] = dz;
+      gbuf[slot][2 * HID + j] = dgn;
+      if (active) {
+        float* gi_o = dgi + pix * 192 + dir * 96;
+        gi_o[j] = dr; gi_o[HID + j] = dz; gi_o[2 * HID + j] = dn;
+        dghn[pix * 64 + dir * HID + j] = dgn;
+        hprev_out[pix * 64 + dir * HID + j] = hp;
+      }
+      __builtin_amdgcn_wave_barrier();
+      f32x2 a0 = {d * z, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
-    for (int i4 = 0; i4 < 3 * HID / 4; ++i4) {
-      const float4 gv = *reinterpret_cast<const float4*>(&gbuf[slot][i4 * 4]);
-      a0 = __builtin_elementwise_fma(wc[2 * i4], f32x2{gv.x, gv.y}, a0);
-      a1 = __builtin_elementwise_fma(wc[2 * i4 + 1], f32x2{gv.z, gv.w}, a1);
+      for (int i4 = 0; i4 < 3 * HID / 4; ++i4) {
+        const float4 gv = *reinterpret_cast<const float4*>(&gbuf[slot][i4 * 4]);
+        a0 = __builtin_elementwise_fma(wc[2 * i4], f32x2{gv.x, gv.y}, a0);
+        a1 = __builtin_elementwise_fma(wc[2 * i4 + 1], f32x2{gv.z, gv.w}, a1);
+      }
+      dh = (a0.x + a1.x) + (a0.y + a1.y);
+      pix += pstep;
     }
-    dh = (a0.x + a1.x) + (a0.y + a1.y);
-    pix += pstep;
-    }
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) c_s[u][e] = q_s[u][e];
-      c_hp[u] = q_hp[u];
-      c_do[u] = q_do[u];
-    }
+  };
+  fetch(0, sA, hA, dA);
+  fetch(PF, sB, hB, dB);
+  for (int t0 = 0; t0 < T; t0 += 3 * PF) {
+    fetch(t0 + 2 * PF, sC, hC, dC);
+    steps(t0, sA, hA, dA);
+    fetch(t0 + 3 * PF, sA, hA, dA);
+    steps(t0 + PF, sB, hB, dB);
+    fetch(t0 + 4 * PF, sB, hB, dB);
+    steps(t0 + 2 * PF, sC, hC, dC);
   }
 }
 

@@ -13,6 +13,8 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
     n = n[: n.index("(")] if "(" in n else n
+    if len(sys.argv) > 3 and sys.argv[3] == "grid":          # one line per (kernel, grid): separates the shapes a GEMM template serves
+        n = f"{n[:46]} [{int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))},{r['Grid_Size_Y']},{r['Grid_Size_Z']}]"
     a = agg[n]; a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 tot = sum(v[1] for v in agg.values())
 print(f"steps={steps}  kernel time per step = {tot / steps / 1e3:.3f} ms  launches per step = {sum(v[0] for v in agg.values()) / steps:.0f}")

@@ -12,5 +12,6 @@ python3 $GRAFT_REPO_ROOT/tools/graph_timeline.py $db 45 > $out/graph_timeline.tx
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/e -o e -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph "$@" > $out/eager_bench.log 2>&1
 csv=$(find $out/e -name "*kernel_trace.csv" | head -1)
 python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $csv 60 > $out/eager_summary.txt 2>&1 || true
+python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $csv 70 grid > $out/eager_by_grid.txt 2>&1 || true
 cp $(find $out/e -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv 2>/dev/null || true
 rm -rf $out/g $out/e
