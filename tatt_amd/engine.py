@@ -105,6 +105,8 @@ class Engine:
             self.ws = torch.empty(WS_FLOATS, device=dev, dtype=torch.float32)
 
     def side_stream(self):
+        if os.environ.get("TATT_NO_FORK") == "1":             # experiment knob: the RPE / text branches on the main stream
+            return torch.cuda.current_stream()
         if self._side is None or self._side.device != self.dev:
             self._side = torch.cuda.Stream(device=self.dev)
         return self._side
@@ -170,6 +172,8 @@ class Engine:
         self._w_keep, self._w_pending, self._w_defer = [], set(), []
 
     def enc_stream(self):
+        if os.environ.get("TATT_NO_FORK") == "1":
+            return torch.cuda.current_stream()
         if self._enc is None or self._enc.device != self.dev:
             self._enc = torch.cuda.Stream(device=self.dev)
         return self._enc

@@ -14,4 +14,5 @@ csv=$(find $out/e -name "*kernel_trace.csv" | head -1)
 python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $csv 60 > $out/eager_summary.txt 2>&1 || true
 python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $csv 70 grid > $out/eager_by_grid.txt 2>&1 || true
 cp $(find $out/e -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv 2>/dev/null || true
+python3 $GRAFT_REPO_ROOT/tools/step_dump.py $db > $out/step_dump.txt 2>&1 || true
 rm -rf $out/g $out/e
