@@ -313,7 +313,10 @@ class Engine:
         self.L.conv_fwd_splitk(dy, self._packed(W, Cout, Cin, k)[1], None, dx, B, H, Wd, Cout, Cin, k, k, Cout, Cin,
                                T * Cout, 1, 0, Cout, acc, 0 if fp32 else self.pf, self._conv_splitk(B * H * Wd, Cin, T * Cout), self.ws)
 
-    def conv_wgrad(self, x, dy, dW, db, B, H, Wd, Cin, Cout, k, fp32=False):
+    def conv_wgrad(self, x, dy, dW, db, B, H, Wd, Cin, Cout, k, fp32=False, bias_grad=True):
+        """bias_grad=False: the convolution feeds a training-mode BatchNorm, whose input gradient sums to zero over the rows for
+        every channel (sum dx = -gamma*invstd*mean(g*xhat)*sum(xhat), and sum(xhat) = 0): the bias gradient is exactly 0 and the
+        16.8 MB column-sum pass that would produce rounding noise around it is not launched (db is left as it is: += 0)."""
         T = k * k
         if Cout <= 16 and Cin <= 64:                           # M = T*Cout (im2col of dY), N = Cin (see tatt_conv_wgrad)
             tiles = -(-(T * Cout) // 128)
@@ -328,7 +331,8 @@ class Engine:
             sk //= 2
         fl = 1 | (0 if fp32 else self.pf)
         self._wgrad(lambda ws: self.L.conv_wgrad(x, dy, dW, B, H, Wd, Cin, Cout, k, k, Cin, Cout, sk, ws, fl), [dy], [x])
-        self.colsum(dy, B * H * Wd, Cout, db)
+        if bias_grad:
+            self.colsum(dy, B * H * Wd, Cout, db)
 
     def bn(self, pre, x, R, C, train, act, out=None, res=None):
         P = self.P
@@ -805,7 +809,7 @@ class Engine:
         self.conv_wgrad(u_in, dcu, G[k8 + "0.conv.weight"], G[k8 + "0.conv.bias"], B, H, W, 64, 256, 3)
         # grad of block1's output (accumulated below) = grad of u_in = bn(c7) + b1: the BatchNorm's reduction runs in the dgrad epilogue
         db1, dc7 = self.conv_dgrad_bn(dcu, P[k8 + "0.conv.weight"], B, H, W, 64, 256, 3, k7 + "1.", c7, st7, 0, training, G)
-        self.conv_wgrad(blk_last, dc7, G[k7 + "0.weight"], G[k7 + "0.bias"], B, H, W, 64, 64, 3)
+        self.conv_wgrad(blk_last, dc7, G[k7 + "0.weight"], G[k7 + "0.bias"], B, H, W, 64, 64, 3, bias_grad=not training)
         dout = self.new(R0, 64)
         self.conv_dgrad(dc7, P[k7 + "0.weight"], dout, B, H, W, 64, 64, 3)
         on_stage("tail")
@@ -824,9 +828,9 @@ class Engine:
             first_tp = False
             self._w_flush()
             dcb = self.bn_bwd_part(pre + "bn2.", cb, dr2, st2, part, nblk, R0, 64, training, G)
-            self.conv_wgrad(ma, dcb, G[pre + "conv2.weight"], G[pre + "conv2.bias"], B, H, W, 64, 64, 3)
+            self.conv_wgrad(ma, dcb, G[pre + "conv2.weight"], G[pre + "conv2.bias"], B, H, W, 64, 64, 3, bias_grad=not training)
             _, dca = self.conv_dgrad_bn(dcb, P[pre + "conv2.weight"], B, H, W, 64, 64, 3, pre + "bn1.", ca, st1, 2, training, G)
-            self.conv_wgrad(blk, dca, G[pre + "conv1.weight"], G[pre + "conv1.bias"], B, H, W, 64, 64, 3)
+            self.conv_wgrad(blk, dca, G[pre + "conv1.weight"], G[pre + "conv1.bias"], B, H, W, 64, 64, 3, bias_grad=not training)
             self.conv_dgrad(dca, P[pre + "conv1.weight"], ds, B, H, W, 64, 64, 3, acc=1)     # dx = ds + conv1^T(dca)
             dout = ds                                            # (no flush here: the conv weight gradients wait for the next SRB's
         axpby(dout, 1.0, None, 0.0, db1, R0 * 64, 1)             #  flush, past its latency-bound GRU kernels: 9.48 -> 9.41 ms)
@@ -959,7 +963,7 @@ class Engine:
             dc = self.bn_bwd(pre + "1.", c, da, stat, Rr, cout, 1, True, G)
             if self.debug is not None:
                 self.debug[f"stn{idx}"] = (dh.clone(), da.clone(), dc.clone())
-            self.conv_wgrad(hin, dc, G[pre + "0.weight"], G[pre + "0.bias"], B, hh, ww, cin, cout, 3, fp32=True)
+            self.conv_wgrad(hin, dc, G[pre + "0.weight"], G[pre + "0.bias"], B, hh, ww, cin, cout, 3, fp32=True, bias_grad=False)  # BN in training mode
             if idx > 0:
                 dh = self.new(Rr, cin)
                 self.conv_dgrad(dc, P[pre + "0.weight"], dh, B, hh, ww, cin, cout, 3, fp32=True)
