@@ -25,36 +25,51 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_IMAGE_TRAIN = 7.70e9        # fwd+bwd, pixel+gradient loss, reference-as-executed
 PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 matrix peak
-CONV_TRAFFIC_BYTES = 34.8e6          # profiles/r01_conv_traffic.md
+CONV_TRAFFIC_BYTES = 34.9e6          # profiles/r02_conv_traffic.md
 
 
 def conv_roofline(L, B, iters=10, bf16=False):
-    """Dominant kernel = gemm_kernel<OP_IM2COL, OP_CONVW_P, FAST>: the NHWC implicit-GEMM convolution (forward and
-    dgrad) over per-step packed weights, 34 launches per training step.  Replays exactly that per-step launch mix
-    (22 x SRB/block7 3x3 64->64 on [B,16,64], the 64<->256 up-sampling conv and its dgrad, 10 STN-head convs) so that
-    the average launch time is comparable with the rocprofv3 --stats average of the same symbol.  Timed with events
-    on the launch stream; algorithmic FLOPs per launch = 2 * pixels * Cout * KH*KW*Cin."""
-    mix = [(16, 64, 64, 64)] * 22 + [(16, 64, 64, 256), (16, 64, 256, 64)]
+    """Dominant kernel = gemm_kernel<OP_IM2COL, OP_CONVW_P, FAST, TAP9, EPI>: the NHWC implicit-GEMM convolution (forward and
+    dgrad) over per-step packed weights, 34 launches per training step.  Replays exactly that per-step launch mix WITH the
+    epilogue variant each launch has in the step -- on [B,16,64]: 11 forward 64->64 with the BatchNorm statistics epilogue
+    (EPI 1), 5 dgrad with the BatchNorm-backward + mish epilogue (EPI 2), 5 dgrad accumulating into the residual gradient and 1
+    plain dgrad (EPI 0), the 64->256 up-sampling conv (EPI 0) and its dgrad (EPI 2, no activation); 10 STN-head convs (EPI 0)
+    -- so that the average launch time is comparable with the rocprofv3 --stats averages of the same symbols.  Timed with
+    events on the launch stream; algorithmic FLOPs per launch = 2 * pixels * Cout * KH*KW*Cin."""
+    srb = (16, 64, 64, 64)
+    mix = [(srb, 1, 0)] * 11 + [(srb, 2, 2)] * 5 + [(srb, 0, 1)] * 5 + [(srb, 0, 0)]          # (shape, epilogue, act | accumulate)
+    mix += [((16, 64, 64, 256), 0, 0), ((16, 64, 256, 64), 2, 0)]
     stn = [(16, 32, 32, 64), (8, 16, 64, 128), (4, 8, 128, 256), (2, 4, 256, 256), (2, 2, 256, 256)]
-    mix += stn + [(h, w, co, ci) for h, w, ci, co in stn]                     # forward + dgrad of the STN stages 1..5
+    mix += [(c, 0, 0) for c in stn] + [((h, w, co, ci), 0, 0) for h, w, ci, co in stn]          # forward + dgrad of the STN stages 1..5
     from tatt_amd.engine import Engine
     ws = torch.empty(8 << 20, device="cuda")
+    fl = 2 if bf16 else 0
     calls, flops = [], 0.0
-    for H, W, Cin, Cout in mix:
+    for (H, W, Cin, Cout), epi, opt in mix:
+        R = B * H * W
         x = torch.randn(B, H, W, Cin, device="cuda")
         wf = torch.randn(Cout * 9 * Cin, device="cuda") * 0.05
         b = torch.randn(Cout, device="cuda")
-        y = torch.empty(B, H, W, Cout, device="cuda")
-        sk = Engine._conv_splitk(B * H * W, Cout, 9 * Cin)                   # the engine splits K on the small STN maps
-        calls.append((x, wf, b, y, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 9 * Cin, 1, 0, Cin, 0, 2 if bf16 else 0, sk, ws))
-        flops += 2.0 * B * H * W * Cout * 9 * Cin
-    for c in calls:
-        L.conv_fwd_splitk(*c)
+        y = torch.zeros(B, H, W, Cout, device="cuda")
+        if epi == 0:
+            sk = Engine._conv_splitk(R, Cout, 9 * Cin)                       # the engine splits K on the small STN maps
+            calls.append((L.conv_fwd_splitk, (x, wf, b, y, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 9 * Cin, 1, 0, Cin, opt, fl, sk, ws)))
+        else:
+            part = torch.empty(-(-R // 128) * 2 * Cout, device="cuda")
+            bnx = torch.randn(R, Cout, device="cuda") if epi == 2 else None
+            stat = torch.stack([torch.zeros(Cout), torch.ones(Cout)]).cuda() if epi == 2 else None
+            ga = torch.ones(Cout, device="cuda") if epi == 2 else None
+            be = torch.zeros(Cout, device="cuda") if epi == 2 else None
+            calls.append((L.conv_fwd_bn, (x, wf, b if epi == 1 else None, y, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 9 * Cin, 1, 0, Cin, fl, epi,
+                                          bnx, Cout, stat, ga, be, opt, part)))
+        flops += 2.0 * R * Cout * 9 * Cin
+    for fn, c in calls:
+        fn(*c)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        for c in calls:
-            L.conv_fwd_splitk(*c)
+        for fn, c in calls:
+            fn(*c)
     e1.record()
     e1.synchronize()
     dt = e0.elapsed_time(e1) / (iters * len(calls)) * 1e-3
@@ -63,15 +78,15 @@ def conv_roofline(L, B, iters=10, bf16=False):
     if bf16:
         # With bf16 operands the same launch is bound by moving its fp32 tensors, not by the matrix core (2.5 PFLOP/s dense):
         # price it against HBM with the algorithmic bytes of an SRB-shaped launch scaled to the mix (in + out + weights, fp32).
-        byts = sum(4.0 * (c[4] * c[5] * c[6] * (c[7] + c[8]) + 9 * c[7] * c[8]) for c in calls) / len(calls)
+        byts = sum(4.0 * (c[4] * c[5] * c[6] * (c[7] + c[8]) + 9 * c[7] * c[8]) for _, c in calls) / len(calls)
         return {"bound": "hbm", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST,BF16> (3x3 conv fwd+dgrad, per-step mix of %d launches)" % len(calls),
                 "achieved": round(byts / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byts / dt / 8e12, 4), "traffic": None,
                 "launch_us": round(dt * 1e6, 2), "bytes_per_launch": byts, "tflops": round(ach, 2), "launches_per_step": len(calls)}
-    return {"bound": "mfma", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST> (3x3 conv fwd+dgrad, per-step mix of %d launches)" % len(calls),
+    return {"bound": "mfma", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST,TAP9,EPI 0|1|2> (3x3 conv fwd+dgrad with the step's epilogue variants, per-step mix of %d launches)" % len(calls),
             "measured": "standalone replay of the step's launch mix on an otherwise idle GPU, HIP events on the launch stream",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": CONV_TRAFFIC_BYTES, "traffic_note": "bytes per SRB-shaped launch (algorithmic 33.7e6): rocprofv3 --pmc 2*FETCH_SIZE"
-            " + WRITE_SIZE, separate passes, profiles/r01_conv_traffic.md (not re-measured by this run)",
+            " + WRITE_SIZE, separate passes, profiles/r02_conv_traffic.md (not re-measured by this run)",
             "launch_us": round(dt * 1e6, 2), "flop_per_launch": fl, "launches_per_step": len(calls)}
 
 

@@ -71,18 +71,23 @@ __device__ __forceinline__ uint32_t tatt_eff_seed(const DropCfg& dc) {
 
 // Activations on the hardware exponential (v_exp_f32, ~1 ulp): one exp each instead of libm's tanhf/log1pf chains.
 //   tanh(softplus(x)) = (n^2 + 2n) / (n^2 + 2n + 2) with n = e^x   (exact identity; saturates to 1 for large x)
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
+// Divisions are v_rcp_f32 (1 ulp) + a multiply: an IEEE fp32 division is a ten-instruction sequence, and these sit on the GRU's
+// per-step latency chain and in the BatchNorm-backward epilogue of the convolutions (16 mish' per lane).  No branches: the
+// exponent argument is clamped where e^x would overflow the rational forms (the result has saturated long before).
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * rcpf_(__expf(2.0f * x) + 1.0f); }
 __device__ __forceinline__ float tanh_softplus_(float x) {
-  if (x > 20.0f) return 1.0f;
-  float n = __expf(x);
-  float t = n * (n + 2.0f);
-  return t / (t + 2.0f);
+  const float n = __expf(fminf(x, 20.0f));
+  const float t = n * (n + 2.0f);
+  return t * rcpf_(t + 2.0f);
 }
 __device__ __forceinline__ float mishf_(float x) { return x * tanh_softplus_(x); }
-__device__ __forceinline__ float mish_gradf_(float x) {
-  float t = tanh_softplus_(x);
-  float s = sigmoidf_(x);
+__device__ __forceinline__ float mish_gradf_(float x) {  // one exponential for both factors: sigmoid(x) = n / (1 + n)
+  const float n = __expf(fminf(x, 20.0f));
+  const float u = n * (n + 2.0f);
+  const float t = u * rcpf_(u + 2.0f);
+  const float s = n * rcpf_(1.0f + n);
   return t + x * (1.0f - t * t) * s;
 }
 
