@@ -42,6 +42,15 @@ __global__ __launch_bounds__(512) void rows(const float* __restrict__ p, int R, 
   if (s == 1.2345f) out[0] = s;
 }
 
+template <int V>
+__global__ __launch_bounds__(512) void wr(float* __restrict__ o, long n) {
+  typedef float vec __attribute__((ext_vector_type(V)));
+  vec* w = reinterpret_cast<vec*>(o);
+  long nv = n / V, i = (long)blockIdx.x * blockDim.x + threadIdx.x, st = (long)gridDim.x * blockDim.x;
+  vec v;
+  for (int k = 0; k < V; ++k) v[k] = (float)threadIdx.x;
+  for (; i < nv; i += st) w[i] = v;
+}
 // 2048 waves (256 blocks x 8), each streaming its own region of len bytes that starts at wave_id * stride: does the spacing of
 // concurrent streams matter (HBM channel interleave)?
 __global__ __launch_bounds__(512) void streams(const char* __restrict__ p, long stride, int len, float* out) {
@@ -101,6 +110,12 @@ int main() {
       snprintf(nm, 64, "rows [%d,%d] ld %d grid %d", R, c * 32, ld, g);
       time([&] { hipLaunchKernelGGL(rows, dim3(g), dim3(512), 0, 0, a, R, ld, c, o); }, nm, (double)R * c * 128);
     }
+  for (int g : {512, 2048}) {
+    char nm[64];
+    snprintf(nm, 64, "write b32  grid %d x512", g); time([&] { hipLaunchKernelGGL(wr<1>, dim3(g), dim3(512), 0, 0, b, n); }, nm, n * 4.0);
+    snprintf(nm, 64, "write b128 grid %d x512", g); time([&] { hipLaunchKernelGGL(wr<4>, dim3(g), dim3(512), 0, 0, b, n); }, nm, n * 4.0);
+    snprintf(nm, 64, "write b128 64MB grid %d", g); time([&] { hipLaunchKernelGGL(wr<4>, dim3(g), dim3(512), 0, 0, b, n / 4); }, nm, n * 1.0);
+  }
   for (long extra : {0L, 256L, 512L, 1024L, 2048L, 4096L, 8192L, 16384L, 32768L}) {
     char nm[64];
     long stride = 98304 + extra;
