@@ -137,6 +137,17 @@ int tatt_rpe_gate_bwd(const float* gi, const float* gh, const float* bhh_f, cons
  * dgh_{s+1} W_hh to the carried d*z and then differentiates the gates of step s (bwd; whhT from tatt_rpe_whh_transpose,
  * dgh_next = NULL on the first call, s = B-1). */
 int tatt_rpe_step_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, const float* hprev, float* hout, float* gh_out, float* qp, int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t stream);
+/* The B forward steps as ONE launch of persistent workgroups: the 8 independent chains (4 blocks of 16 rows x 2 directions) run one
+ * per XCD (chain = XCC id + n_xcd * group; n_xcd from hipDeviceAttributeNumberOfXccs), 32 workgroups per chain keep their W_hh slice in
+ * registers and hand h_s over through flag lines in that XCD's L2; every wait is bounded.  No counterpart call in the reference (it is
+ * nn.GRU's time loop, model/transformer_v2.py:177,:215-221).  hstep [2][B+1][64][512] (h_0 set by the caller), gh_all [2][B][64][1536];
+ * sync: device buffer of tatt_rpe_chain_sync_words(B) uint32, zeroed by the call on `stream`; sync[1] != 0 afterwards = a wait gave
+ * up (results invalid).  Needs the GPU's CUs free enough to hold 32 workgroups of 512 threads per XCD at once; two calls that
+ * share a sync buffer must not overlap. */
+size_t tatt_rpe_chain_sync_words(int B);
+int tatt_rpe_chain_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* hstep, float* gh_all, float* qp, int B, long dir_stride_gh, long dir_stride_h, uint32_t* sync, hipStream_t stream);
+/* The B BPTT steps (s = B-1 .. 0) as ONE launch, same scheme; carry in/out and dgi_sum accumulated as by tatt_rpe_step_bwd; a sync buffer of its own. */
+int tatt_rpe_chain_bwd(const float* gi, const float* gh_all, const float* bhh_f, const float* bhh_b, const float* hstep, const float* dqp, float* carry, float* dgh_all, float* dgi_sum, const float* whhT, int B, long dir_stride_gh, long dir_stride_h, uint32_t* sync, hipStream_t stream);
 int tatt_rpe_whh_transpose(const float* whh_f, const float* whh_b, float* whhT, hipStream_t stream);
 int tatt_rpe_step_bwd(const float* gi, const float* gh, const float* bhh_f, const float* bhh_b, const float* hprev, const float* dqp, float* carry, const float* dgh_next, float* dgh_out, float* dgi_sum, const float* whhT, int s, int B, long dir_stride_gh, long dir_stride_h, hipStream_t stream);
 int tatt_rpe_gather_x(const float* init_factor, float* x, hipStream_t stream);

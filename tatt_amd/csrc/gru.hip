@@ -359,6 +359,157 @@ __global__ __launch_bounds__(64 * NWV) void rpe_step_fwd(const float* __restrict
   qp[(((long)tt * 16 + (f >> 6)) * RW + w) * 64 + (f & 63)] = h;
 }
 
+// ---- the whole forward chain as ONE launch, one XCD per (row block, direction) ---------------------------------------------------
+// The 64 rows of the recurrence are independent chains, and 4 row blocks of 16 x 2 directions = 8 = the number of XCDs.  XCD x runs
+// the chain of (row block x & 3, direction x >> 2) entirely inside its own L2: 32 persistent workgroups (one per 16 hidden units =
+// 48 gate columns), each holding its 96 KB slice of W_hh in registers for all B steps and exchanging the 16 x 512 state through L2
+// (a CU's stores write through to it) so that a step costs the hand-over inside one L2 + the product
+// (6.4 us measured), where a kernel boundary per step cost 9.4 us in a graph and 12 us launched eagerly (launch gap, cold caches,
+// W_hh re-read every step).
+//   * Which XCD a workgroup is on is read from the hardware (HW_REG_XCC_ID), not inferred from its id, and which chain an XCD runs
+//     follows from that id and the device's XCD count (chain_role below): nothing depends on the dispatcher's placement order beyond
+//     every XCD receiving its share of the grid.  The launch oversubscribes (grid = 2 x 256 workgroups); the ones not needed exit at once.
+//   * Hand-over: an owner stores its 16 x 16 block of h_{s+1}, waits until the stores have reached L2 (vmcnt(0)), then writes "s+1" into
+//     its flag word -- one copy per reader, so that every reader polls a 128-byte line of its own.  A reader polls with ONE returning
+//     L2 atomic (OR of 0) on its 32 flag words -- a plain load could be served from the CU's cache for ever -- and then reads h_s with
+//     ordinary loads: nobody touches those lines before they are complete, so the CU cannot hold a stale copy of them.
+//     Tried on the way (tools/micro_rpe_chain.py, us per step): polling the data itself against a NaN sentinel with device-scope loads
+//     6.8 (through the fabric), with L2 atomics 34, behind an L1 invalidate (`buffer_inv sc1`) 47, flag counters bumped by 256
+//     same-address device atomics 34; per-step kernels in a graph 9.4; this scheme 6.4, of which 1.3 are the product itself (0.2 GFLOP
+//     per step is the whole chip's fp32 matrix rate for 1.3 us) and about 2 each the flag hand-over and the h read.
+//   * A workgroup only waits for the other 31 owners of ITS XCD, all of which have started (they hold tickets): no deadlock, no
+//     grid-wide barrier.  The wait is bounded all the same: after RPE_SPIN_LIMIT polls a workgroup sets sync[1] and carries on
+//     with what is there (wrong numbers and an error flag, never a hang) -- e.g. if an XCD ever received fewer than 32 workgroups.
+//   * gh and query_pos are only read by later kernels (ordinary stores; visible at the end of the kernel like any output).
+constexpr unsigned RPE_SPIN_LIMIT = 1u << 18;  // polls of ~1-2 us each before a reader gives up
+constexpr int RPE_SYNC_WORDS = 32 * 9 + 8 * 1024;          // sync[1] error flags; sync[32 * (1 + x)] XCD x's ticket counter (a line of its own); then per chain [reader 32][writer 32] flag words
+// read a word AT the L2 of this XCD (returning atomic OR of 0: a plain load could be served from the CU's cache for ever)
+__device__ __forceinline__ unsigned l2_read(unsigned* p) {
+  unsigned v;
+  const unsigned zero = 0u;
+  asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p), "v"(zero) : "memory");
+  return v;
+}
+// Which of the 8 chains (row block mh, direction dir) this workgroup works on and which 16 hidden units (jb); false: not needed, exit.
+// Workgroups that arrive on the same XCD form groups of 32 in arrival order (a ticket from that XCD's counter, an L2 atomic); group k
+// of XCD x runs chain x + nxcd * k (nxcd = hipDeviceAttributeNumberOfXccs, passed by the host).  On MI355X (8 XCDs, grid = 512
+// dealt round-robin) the first group of every XCD gets that XCD's chain and the second exits; with fewer XCDs visible (another
+// partition mode) an XCD runs several chains -- every chain still lives inside one L2.  (An earlier version drew the chain from a
+// device-wide counter: in a graph, next to other kernels, an XCD that started late lost its chain to the SECOND group of an early
+// one, two chains then shared one XCD and the step was 0.3 ms slower than with per-step launches.)
+__device__ __forceinline__ bool chain_role(unsigned* sync, int nxcd, int& jb, int& mh, int& dir, unsigned*& flags) {
+  __shared__ unsigned s_role[2];
+  if (threadIdx.x == 0) {
+    const int x = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15) % nxcd;  // HW_REG_XCC_ID[3:0]
+    unsigned* line = sync + 32 * (1 + x);  // this XCD's own 128-byte line: [0] tickets
+    const unsigned t = __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    s_role[0] = (unsigned)x + (unsigned)nxcd * (t >> 5);
+    s_role[1] = t & 31;
+  }
+  __syncthreads();
+  const unsigned role = s_role[0];
+  jb = (int)s_role[1];
+  mh = (int)(role & 3);
+  dir = (int)((role >> 2) & 1);
+  flags = sync + 32 * 9 + 1024 * (role & 7);  // this chain's flag words: [reader 32][writer 32], a 128-byte line per reader
+  return role < 8u;
+}
+
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void rpe_chain_fwd(const float* __restrict__ gi, const float* __restrict__ whh_f,
+                                                          const float* __restrict__ whh_b, const float* __restrict__ bhh_f,
+                                                          const float* __restrict__ bhh_b, float* hstep, float* __restrict__ gh_all,
+                                                          float* __restrict__ qp, int B, long dir_stride_gh, long dir_stride_h,
+                                                          unsigned* sync, int nxcd) {
+  constexpr int NE = RH / NWV / 16;
+  __shared__ float red[NWV][16][49];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, q = lane >> 4;
+  int jb, mh, dir;
+  unsigned* flags;
+  if (!chain_role(sync, nxcd, jb, mh, dir, flags)) return;
+  const float* W = dir ? whh_b : whh_f;
+  const int kbase = wv * (RH / NWV) + q * 4;
+  // ---- once for the whole chain: the W_hh slice and the (time-invariant) gate operands ----
+  float4 bf[3][NE];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const float* pb = W + (long)(g * RH + jb * 16 + i) * RH + kbase;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) bf[g][e] = *reinterpret_cast<const float4*>(pb + 16 * e);
+  }
+  const int gt = tid & 255;
+  const int wl = gt >> 4, jj = gt & 15, w = mh * 16 + wl, j = jb * 16 + jj;
+  const float* g_i = gi + ((long)dir * RW + w) * 3 * RH;
+  const float* bh = dir ? bhh_b : bhh_f;
+  const float gir = g_i[j], giz = g_i[RH + j], gin = g_i[2 * RH + j];
+  const float br = bh[j], bz = bh[RH + j], bn = bh[2 * RH + j];
+  float hpv = hstep[dir * dir_stride_h + (long)w * RH + j];  // h_0; afterwards this thread's own previous output
+  float gh_s[3] = {0.f, 0.f, 0.f};
+  for (int s = 0; s < B; ++s) {
+    const long hoff = dir * dir_stride_h + (long)s * RW * RH;  // h_s of this direction; h_{s+1} follows RW * RH floats later
+    // ---- h_s of this row block: written by this XCD's 32 owners in step s-1, each of which then set its flag word to s ----
+    if (s > 0) {
+      for (unsigned it = 0;; ++it) {
+        unsigned f = 0xffffffffu;
+        if (tid < 32) f = l2_read(flags + jb * 32 + tid);
+        if (__syncthreads_and(f >= (unsigned)s)) break;
+        if (it > RPE_SPIN_LIMIT) {  // never a hang: give up, flag it, carry on with what is there
+          if (tid == 0) __hip_atomic_fetch_or(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    // first touch of these lines by this CU in this launch (nobody reads h_s before it is complete): ordinary loads, served by L2
+    float4 af[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) af[e] = *reinterpret_cast<const float4*>(hstep + hoff + (long)(mh * 16 + i) * RH + kbase + 16 * e);
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) mfma4(acc[g], af[e], bf[g][e]);
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wv][4 * q + r][g * 16 + i] = acc[g][r];
+    __syncthreads();
+    if (tid < 256) {
+      float gh[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        float t = 0.f;
+#pragma unroll
+        for (int v = 0; v < NWV; v += 2) t += red[v][wl][g * 16 + jj] + red[v + 1][wl][g * 16 + jj];
+        gh[g] = t;
+      }
+      const float r = sigmoidf_(gir + gh[0] + br);
+      const float z = sigmoidf_(giz + gh[1] + bz);
+      const float n = tanhf_(gin + r * (gh[2] + bn));
+      const float h = (1.f - z) * n + z * hpv;
+      hpv = h;
+      hstep[hoff + (long)RW * RH + (long)w * RH + j] = h;
+      gh_s[0] = gh[0]; gh_s[1] = gh[1]; gh_s[2] = gh[2];
+    }
+    // publish: every thread's h store has reached L2 (vmcnt(0)), then this workgroup's flag word says "s + 1 steps done"
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid < 32) *reinterpret_cast<volatile unsigned*>(flags + tid * 32 + jb) = (unsigned)s + 1u;  // one copy per reader: each polls its own line
+    if (tid < 256) {  // off the chain's critical path: what only later kernels read
+      float* go = gh_all + dir * dir_stride_gh + ((long)s * RW + w) * 3 * RH;
+      go[j] = gh_s[0];
+      go[RH + j] = gh_s[1];
+      go[2 * RH + j] = gh_s[2];
+      const int tt = dir ? B - 1 - s : s;
+      const int f = dir * RH + j;
+      qp[(((long)tt * 16 + (f >> 6)) * RW + w) * 64 + (f & 63)] = hpv;
+    }
+  }
+}
+
 // whhT[dir][j][i] = whh_dir[i][j]  ([1536][512] -> [512][1536]); once per backward pass
 __global__ void rpe_whh_transpose(const float* __restrict__ whh_f, const float* __restrict__ whh_b, float* __restrict__ whhT) {
   __shared__ float t[32][33];
@@ -469,6 +620,115 @@ __global__ __launch_bounds__(64 * NWV) void rpe_step_bwd(const float* __restrict
   }
 }
 
+// ---- the BPTT chain as ONE launch: same placement as rpe_chain_fwd (XCD = (row block, direction), 32 persistent owners of 16 hidden
+// units each).  Per step s = B-1 .. 0 an owner needs dgh_{s+1} of its 16 rows -- written by its XCD's 32 owners one step earlier,
+// handed over through the same per-reader flag lines -- multiplies it with its 96 KB slice of W_hh (transposed; in registers for the
+// whole chain), and differentiates the gates of step s for its 16 x 16 elements.  The carried d*z and the running sum of dgi belong to
+// one thread each for the whole chain: registers, read from / added to memory once.
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void rpe_chain_bwd(const float* __restrict__ gi, const float* __restrict__ gh_all,
+                                                          const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
+                                                          const float* __restrict__ hstep, const float* __restrict__ dqp,
+                                                          float* __restrict__ carry, float* dgh_all, float* __restrict__ dgi_sum,
+                                                          const float* __restrict__ whhT, int B, long dir_stride_gh, long dir_stride_h,
+                                                          unsigned* sync, int nxcd) {
+  constexpr int KW = 3 * RH / NWV, CH = KW / 3, NE = CH / 16;  // K range of a wave, in three chunks of NE float4 steps
+  __shared__ float red[NWV][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, q = lane >> 4;
+  int jb, mh, dir;
+  unsigned* flags;
+  if (!chain_role(sync, nxcd, jb, mh, dir, flags)) return;
+  // ---- once for the whole chain: the W_hh^T slice and the time-invariant gate operands ----
+  float4 bf[3][NE];
+  {
+    const float* Bt = whhT + ((long)dir * RH + jb * 16 + i) * 3 * RH + wv * KW + q * 4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int e = 0; e < NE; ++e) bf[c][e] = *reinterpret_cast<const float4*>(Bt + c * CH + 16 * e);
+  }
+  const int gt = tid & 255;
+  const int wl = gt >> 4, jj = gt & 15, w = mh * 16 + wl, j = jb * 16 + jj;
+  const float* bh = dir ? bhh_b : bhh_f;
+  const float* g_i = gi + ((long)dir * RW + w) * 3 * RH;
+  const float g_ir = g_i[j], g_iz = g_i[RH + j], g_in = g_i[2 * RH + j];
+  const float g_br = bh[j], g_bz = bh[RH + j], g_bn = bh[2 * RH + j];
+  const long ci = ((long)dir * RW + w) * RH + j;
+  float cr = carry[ci];                      // d_{s+1} z_{s+1}: this thread's own, step after step
+  float sum_r = 0.f, sum_z = 0.f, sum_n = 0.f;  // this element's share of dgi_sum
+  for (int s = B - 1; s >= 0; --s) {
+    // what this step needs from the forward pass and from the loss: independent of the chain, requested before the wait
+    const float* g_h = gh_all + dir * dir_stride_gh + ((long)s * RW + w) * 3 * RH;
+    const float g_hr = g_h[j], g_hz = g_h[RH + j], g_hn = g_h[2 * RH + j];
+    const float hp = hstep[dir * dir_stride_h + ((long)s * RW + w) * RH + j];
+    const int tt = dir ? B - 1 - s : s;
+    const int f = dir * RH + j;
+    const float dq = dqp[(((long)tt * 16 + (f >> 6)) * RW + w) * 64 + (f & 63)];
+    float c = cr;
+    if (s + 1 < B) {
+      // ---- dgh_{s+1} of this row block: every owner of this XCD has set its flag word to B - 1 - s once it was stored ----
+      for (unsigned it = 0;; ++it) {
+        unsigned fl = 0xffffffffu;
+        if (tid < 32) fl = l2_read(flags + jb * 32 + tid);
+        if (__syncthreads_and(fl >= (unsigned)(B - 1 - s))) break;
+        if (it > RPE_SPIN_LIMIT) {
+          if (tid == 0) __hip_atomic_fetch_or(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const float* A = dgh_all + dir * dir_stride_gh + ((long)(s + 1) * RW + mh * 16 + i) * 3 * RH + wv * KW + q * 4;
+      float4 af[3][NE];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) af[cc][e] = *reinterpret_cast<const float4*>(A + cc * CH + 16 * e);
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) mfma4(acc, af[cc][e], bf[cc][e]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wv][4 * q + r][i] = acc[r];
+      __syncthreads();
+      if (tid < 256) {
+#pragma unroll
+        for (int v = 0; v < NWV; v += 2) c += red[v][wl][jj] + red[v + 1][wl][jj];
+      }
+    }
+    if (tid < 256) {
+      const float ghn = g_hn + g_bn;
+      const float r = sigmoidf_(g_ir + g_hr + g_br);
+      const float z = sigmoidf_(g_iz + g_hz + g_bz);
+      const float n = tanhf_(g_in + r * ghn);
+      const float d = c + dq;
+      const float dn = d * (1.f - z) * (1.f - n * n);
+      const float dz = d * (hp - n) * z * (1.f - z);
+      const float dr = dn * ghn * r * (1.f - r);
+      float* o = dgh_all + dir * dir_stride_gh + ((long)s * RW + w) * 3 * RH;
+      o[j] = dr;
+      o[RH + j] = dz;
+      o[2 * RH + j] = dn * r;
+      sum_r += dr;
+      sum_z += dz;
+      sum_n += dn;
+      cr = d * z;
+    }
+    // publish: the dgh stores have reached L2, then "B - s steps done" into this owner's flag word of every reader
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid < 32) *reinterpret_cast<volatile unsigned*>(flags + tid * 32 + jb) = (unsigned)(B - s);
+  }
+  if (tid < 256) {
+    float* gs = dgi_sum + ((long)dir * RW + w) * 3 * RH;
+    gs[j] += sum_r;
+    gs[RH + j] += sum_z;
+    gs[2 * RH + j] += sum_n;
+    carry[ci] = cr;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -480,6 +740,52 @@ int tatt_rpe_step_fwd(const float* gi, const float* whh_f, const float* whh_b, c
   hipLaunchKernelGGL(rpe_step_fwd<8>, dim3(RH / 4, 2), dim3(512), 0, st, gi, whh_f, whh_b, bhh_f, bhh_b, hprev, hout, gh_out, qp, s, B,
                      dir_stride_gh, dir_stride_h);
   TATT_LAUNCH_CHECK("rpe_step_fwd");
+  return TATT_OK;
+}
+
+// Words of the `sync` buffer of the chain launches (uint32; zeroed by the call itself): error flag + one ticket counter per XCD.
+// XCDs of the current device (8 on MI355X in its default partition mode); no allocation, no synchronisation, legal under capture
+static int rpe_num_xcd() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || n < 1 || n > 8) n = 8;
+  return n;
+}
+
+size_t tatt_rpe_chain_sync_words(int B) { (void)B; return (size_t)RPE_SYNC_WORDS; }
+
+// All B steps of tatt_rpe_step_fwd in one launch (see rpe_chain_fwd).  hstep [2][B+1][64][512] with h_0 = hstep[:, 0] set by the caller,
+// gh_all [2][B][64][1536]; sync: tatt_rpe_chain_sync_words(B) uint32 of device memory; after the launch sync[1] != 0 means a workgroup
+// gave up waiting for its predecessor step (the results are then invalid).
+int tatt_rpe_chain_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* hstep,
+                       float* gh_all, float* qp, int B, long dir_stride_gh, long dir_stride_h, uint32_t* sync, hipStream_t st) {
+  TATT_CHECK_ARG(gi && whh_f && whh_b && bhh_f && bhh_b && hstep && gh_all && qp && sync && B > 0 && B <= 4096, "tatt_rpe_chain_fwd: bad arguments");
+  TATT_CHECK_ARG(2L * (B + 1) * RW * RH * 4 < (1L << 31) && dir_stride_h >= (long)(B + 1) * RW * RH, "tatt_rpe_chain_fwd: hstep too large / bad stride");
+  const int nxcd = rpe_num_xcd();
+  if (hipMemsetAsync(sync, 0, tatt_rpe_chain_sync_words(B) * 4, st) != hipSuccess) {
+    tatt_set_error("tatt_rpe_chain_fwd: hipMemsetAsync failed");
+    return TATT_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(rpe_chain_fwd<8>, dim3(2 * 256), dim3(512), 0, st, gi, whh_f, whh_b, bhh_f, bhh_b, hstep, gh_all, qp, B, dir_stride_gh,
+                     dir_stride_h, sync, nxcd);
+  TATT_LAUNCH_CHECK("rpe_chain_fwd");
+  return TATT_OK;
+}
+
+// All B steps of tatt_rpe_step_bwd (s = B-1 .. 0) in one launch: gh_all / dgh_all [2][B][64][1536], hstep [2][B+1][64][512], carry and
+// dgi_sum as for the step kernel (carry in / out, dgi_sum accumulated); sync as for tatt_rpe_chain_fwd (a buffer of its own).
+int tatt_rpe_chain_bwd(const float* gi, const float* gh_all, const float* bhh_f, const float* bhh_b, const float* hstep, const float* dqp,
+                       float* carry, float* dgh_all, float* dgi_sum, const float* whhT, int B, long dir_stride_gh, long dir_stride_h,
+                       uint32_t* sync, hipStream_t st) {
+  TATT_CHECK_ARG(gi && gh_all && bhh_f && bhh_b && hstep && dqp && carry && dgh_all && dgi_sum && whhT && sync && B > 0 && B <= 4096,
+                 "tatt_rpe_chain_bwd: bad arguments");
+  const int nxcd = rpe_num_xcd();
+  if (hipMemsetAsync(sync, 0, tatt_rpe_chain_sync_words(B) * 4, st) != hipSuccess) {
+    tatt_set_error("tatt_rpe_chain_bwd: hipMemsetAsync failed");
+    return TATT_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(rpe_chain_bwd<8>, dim3(2 * 256), dim3(512), 0, st, gi, gh_all, bhh_f, bhh_b, hstep, dqp, carry, dgh_all, dgi_sum, whhT, B,
+                     dir_stride_gh, dir_stride_h, sync, nxcd);
+  TATT_LAUNCH_CHECK("rpe_chain_bwd");
   return TATT_OK;
 }
 

@@ -22,6 +22,7 @@ DROP_SITES = {
 }
 STN_STAGES = [(0, 4, 32, (2, 2)), (2, 32, 64, (2, 2)), (4, 64, 128, (2, 2)), (6, 128, 256, (2, 2)),
               (8, 256, 256, (1, 2)), (10, 256, 256, None)]
+RPE_CHAIN = os.environ.get("TATT_RPE_CHAIN", "1") != "0"   # 0: one launch per step of the RPE recurrence (A/B runs)
 WS_FLOATS = 48 * 1024 * 1024
 NODROP = (0, 0, 1.0, None)
 
@@ -163,6 +164,15 @@ class Engine:
         """Call before the main stream writes `t` in place: if a pending weight-gradient kernel still reads it, join first."""
         if self._w_pending and t is not None and t.untyped_storage().data_ptr() in self._w_pending:
             self._w_join()
+
+    def check_rpe_chain(self):
+        """Raise if a single-launch RPE chain (tatt_rpe_chain_fwd / _bwd) of the last pass reported a reader that gave up waiting
+        (sync word 1 != 0: the pass's numbers are then invalid).  Synchronises; call it at check points, not per step."""
+        for name in ("_rpe_sync", "_rpe_sync_b"):
+            t = getattr(self, name, None)
+            if t is not None and int(t[1].item()) != 0:
+                raise RuntimeError(f"RPE chain kernel ({name}) gave up waiting for its predecessor step (flag {int(t[1].item())}): results "
+                                   "are invalid; set TATT_RPE_CHAIN=0 to run the recurrence as one launch per step")
 
     def reset_streams(self):
         """Drop every forked stream and queued weight-gradient launch (after a failed hipGraph capture the old streams may be
@@ -622,9 +632,14 @@ class Engine:
             dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                for s in range(B):  # one fused launch per step: h_s W_hh^T, gates, h_{s+1}, query_pos (tatt_rpe_step_fwd)
-                    L.rpe_step_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], hstep[0, s + 1],
-                                   gh_all[0, s], qp, s, B, dsg, dsh)
+                if RPE_CHAIN:   # the whole chain as one launch of persistent workgroups (tatt_rpe_chain_fwd)
+                    self._rpe_sync = torch.empty(L.rpe_chain_sync_words(B), device=self.dev, dtype=torch.int32)
+                    L.rpe_chain_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep, gh_all, qp, B, dsg, dsh,
+                                    self._rpe_sync)
+                else:
+                    for s in range(B):  # one fused launch per step: h_s W_hh^T, gates, h_{s+1}, query_pos (tatt_rpe_step_fwd)
+                        L.rpe_step_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], hstep[0, s + 1],
+                                       gh_all[0, s], qp, s, B, dsg, dsh)
 
         # ---- text branch of the TP interpreter (fc_in, PReLU, positional encoding, encoder layer): it reads the prior and weights
         # only, so it runs on a stream of its own beside the STN head / block1 (and the RPE chain) until the decoder needs it
@@ -886,9 +901,14 @@ class Engine:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 L.rpe_whh_transpose(whh_f, whh_b, whhT)
-                for s in reversed(range(B)):
-                    L.rpe_step_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
-                                   dgh_all[0, s + 1] if s + 1 < B else None, dgh_all[0, s], dgi_sum, whhT, s, B, dsg, dsh)
+                if RPE_CHAIN:   # the whole BPTT chain as one launch of persistent workgroups (tatt_rpe_chain_bwd)
+                    self._rpe_sync_b = torch.empty(L.rpe_chain_sync_words(B), device=self.dev, dtype=torch.int32)
+                    L.rpe_chain_bwd(gi, gh_all, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep, dqp, carry, dgh_all, dgi_sum, whhT,
+                                    B, dsg, dsh, self._rpe_sync_b)
+                else:
+                    for s in reversed(range(B)):
+                        L.rpe_step_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
+                                       dgh_all[0, s + 1] if s + 1 < B else None, dgh_all[0, s], dgi_sum, whhT, s, B, dsg, dsh)
 
         def rpe_finish():
             if owner is not None:

@@ -209,8 +209,9 @@ class SRTrainer:
                          self.max_norm, self.state, self.ws)
 
     def verify_replicas(self):
-        """Raise unless every rank holds bit-identical parameters and optimiser moments; returns the rank count RCCL reports
-        through a collective (1 without a process group)."""
+        """Raise unless every rank holds bit-identical parameters and optimiser moments (and the RPE chain kernels of the last step
+        completed without a timed-out wait); returns the rank count RCCL reports through a collective (1 without a process group)."""
+        self.eng.check_rpe_chain()
         if not self.dp:
             return 1
         n = assert_replicas_identical(self.flat_p, "SR parameters")

@@ -312,10 +312,11 @@ def test_gru32_fwd_bwd(vertical):
     close(dx.view(B, H, W, 64), x.grad, 5e-5, "gru dx")
 
 
-def test_rpe_fused_steps_vs_torch_gru():
+@pytest.mark.parametrize("B,chain", [(5, False), (5, True), (64, True), (3, True)])
+def test_rpe_fused_steps_vs_torch_gru(B, chain):
     """tatt_rpe_step_fwd / _bwd (one launch per step of the GRU(1024 -> 2x512) that runs over the batch axis with the
-    same input at every step) against nn.GRU autograd in fp64."""
-    B = 5
+    same input at every step) and tatt_rpe_chain_fwd / _bwd (all B steps in one launch of persistent workgroups, B = 64 is the
+    BASELINE chain length) against nn.GRU autograd in fp64."""
     torch.manual_seed(0)
     gru = torch.nn.GRU(1024, 512, bidirectional=True).double()
     x = rnd(64, 1024).double()
@@ -331,9 +332,14 @@ def test_rpe_fused_steps_vs_torch_gru():
     qp = torch.empty(B, 16, 64, 64, device="cuda")
     dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
     bf, bb = W["bias_hh_l0"], W["bias_hh_l0_reverse"]
-    for s_ in range(B):
-        L().rpe_step_fwd(gi, W["weight_hh_l0"], W["weight_hh_l0_reverse"], bf, bb, hstep[0, s_], hstep[0, s_ + 1], gh_all[0, s_], qp,
-                         s_, B, dsg, dsh)
+    sync = torch.full((L().rpe_chain_sync_words(B),), 7, device="cuda", dtype=torch.int32)      # the call zeroes it itself
+    if chain:
+        L().rpe_chain_fwd(gi, W["weight_hh_l0"], W["weight_hh_l0_reverse"], bf, bb, hstep, gh_all, qp, B, dsg, dsh, sync)
+        assert int(sync[1]) == 0, "a reader of the forward chain gave up waiting"
+    else:
+        for s_ in range(B):
+            L().rpe_step_fwd(gi, W["weight_hh_l0"], W["weight_hh_l0_reverse"], bf, bb, hstep[0, s_], hstep[0, s_ + 1], gh_all[0, s_], qp,
+                             s_, B, dsg, dsh)
     close(qp.permute(0, 2, 1, 3).reshape(B, 64, 1024), out.detach(), what="rpe out")
     dqp = cu(dout.float().view(B, 64, 16, 64).permute(0, 2, 1, 3))
     carry = torch.zeros(2, 64, 512, device="cuda")
@@ -342,9 +348,13 @@ def test_rpe_fused_steps_vs_torch_gru():
     whhT = torch.empty(2, 512, 1536, device="cuda")
     L().rpe_whh_transpose(W["weight_hh_l0"], W["weight_hh_l0_reverse"], whhT)
     assert torch.equal(whhT[1], W["weight_hh_l0_reverse"].T)
-    for s_ in reversed(range(B)):
-        L().rpe_step_bwd(gi, gh_all[0, s_], bf, bb, hstep[0, s_], dqp, carry, dgh_all[0, s_ + 1] if s_ + 1 < B else None,
-                         dgh_all[0, s_], dgi_sum, whhT, s_, B, dsg, dsh)
+    if chain:
+        L().rpe_chain_bwd(gi, gh_all, bf, bb, hstep, dqp, carry, dgh_all, dgi_sum, whhT, B, dsg, dsh, sync)
+        assert int(sync[1]) == 0, "a reader of the backward chain gave up waiting"
+    else:
+        for s_ in reversed(range(B)):
+            L().rpe_step_bwd(gi, gh_all[0, s_], bf, bb, hstep[0, s_], dqp, carry, dgh_all[0, s_ + 1] if s_ + 1 < B else None,
+                             dgh_all[0, s_], dgi_sum, whhT, s_, B, dsg, dsh)
     for d, sx in enumerate(sfx):
         close(dgi_sum[d].sum(0), getattr(gru, "bias_ih_l0" + sx).grad, what="db_ih" + sx)
         close(dgi_sum[d].T @ cu(x.float()), getattr(gru, "weight_ih_l0" + sx).grad, what="dW_ih" + sx)

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(64 * SW) __attribute__((amdgpu_waves_per_eu(NT <= 2
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       i32x4s v = __builtin_amdgcn_raw_buffer_load_b128(rs, live ? vo[j] : (int)0x80000000, so, 0);
-      ra[j] = make_float4(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y), __builtin_bit_cast(float, v.z), __builtin_bit_cast(float, v.w));
+      ra[j] = *reinterpret_cast<float4*>(&v);  // (component-wise bit_casts of the result compile to a one-dword load on this toolchain:
+      // the timings in DESIGN.md were taken with that defect, i.e. with a quarter of the A traffic, and were still not faster)
     }
     if (++t_kt == KT) {
       t_kt = 0;
