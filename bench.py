@@ -28,7 +28,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 matrix peak
 CONV_TRAFFIC_BYTES = 34.9e6          # profiles/r02_conv_traffic.md
 
 
-def conv_roofline(L, B, iters=10, bf16=False):
+def conv_roofline(L, B, iters=10, bf16=False, x3=False):
     """Dominant kernel = gemm_kernel<OP_IM2COL, OP_CONVW_P, FAST, TAP9, EPI>: the NHWC implicit-GEMM convolution (forward and
     dgrad) over per-step packed weights, 34 launches per training step.  Replays exactly that per-step launch mix WITH the
     epilogue variant each launch has in the step -- on [B,16,64]: 11 forward 64->64 with the BatchNorm statistics epilogue
@@ -43,7 +43,7 @@ def conv_roofline(L, B, iters=10, bf16=False):
     mix += [(c, 0, 0) for c in stn] + [((h, w, co, ci), 0, 0) for h, w, ci, co in stn]          # forward + dgrad of the STN stages 1..5
     from tatt_amd.engine import Engine
     ws = torch.empty(8 << 20, device="cuda")
-    fl = 2 if bf16 else 0
+    fl = 2 if bf16 else 4 if x3 else 0
     calls, flops = [], 0.0
     for (H, W, Cin, Cout), epi, opt in mix:
         R = B * H * W
@@ -125,6 +125,9 @@ def main():
                                                       "BASELINE config 3's step in fp32; off = config 2, the default metric")
     ap.add_argument("--bf16", action="store_true", help="matrix-core operands in bf16 (fp32 accumulate, fp32 tensors in memory): "
                                                        "with --tsc this is BASELINE config 3's arithmetic; off = fp32, the default metric")
+    ap.add_argument("--f32x3", action="store_true", help="fp32 products of the trunk convolutions computed on the bf16 matrix core from "
+                                                        "three bf16 pieces per operand (six terms, fp32 accumulate; error at the level "
+                                                        "of the fp32 FMA chain): opt-in, the default metric uses fp32 MFMA")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,7 +150,7 @@ def main():
                           text_embedding=a.K)
     state_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.cuda().train()
-    model.matmul_precision = "bf16" if a.bf16 else "fp32"
+    model.matmul_precision = "bf16" if a.bf16 else "f32x3" if a.f32x3 else "fp32"
     kw = dict(lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, loss_weight=(1.0, 1e-4), use_graph=not a.no_graph, tsc=a.tsc)
     if a.full:
         from tatt_amd.model.crnn import CRNN
@@ -200,7 +203,7 @@ def main():
 
     if rank == 0:
         ms = dt / a.steps * 1e3
-        prec = "bf16" if a.bf16 else "fp32"
+        prec = "bf16" if a.bf16 else "fp32 (3 x 3 convolutions: 3-piece bf16 split products, fp32 accumulate)" if a.f32x3 else "fp32"
         value = a.batch * world * a.steps / dt
         out = {
             "metric": "train images/sec (whole node) TATT 16x64->32x128", "value": round(value, 1), "unit": "images/sec",
@@ -223,7 +226,7 @@ def main():
         }
         if dp:
             out["data_parallel"] = dp
-        out["roofline"] = conv_roofline(lib(), a.batch, bf16=a.bf16)
+        out["roofline"] = conv_roofline(lib(), a.batch, bf16=a.bf16, x3=a.f32x3)
         if world == 1 and not a.no_cpu_baseline and not a.tsc and not a.full:
             out["cpu_baseline"] = cpu_baseline(state_cpu, a.batch, a.K)
         print(json.dumps(out), flush=True)

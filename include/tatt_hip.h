@@ -26,6 +26,7 @@ typedef void* hipStream_t;
 #define TATT_RELU 1
 #define TATT_ACCUMULATE 1
 #define TATT_BF16 2
+#define TATT_F32X3 4
 
 #ifdef __cplusplus
 extern "C" {
@@ -43,6 +44,13 @@ int tatt_version(void);
  *                          (BASELINE.json config 3; the reference itself has no autocast).  Default = exact fp32 operands on
  *                          v_mfma_f32_32x32x2_f32, the parity path.  Launches whose shapes take the generic (non-FAST) loaders
  *                          stay fp32 either way; tensors in memory are fp32 in both modes.
+ *     TATT_F32X3 (4)       opt-in: fp32 products on the bf16 matrix core.  Every operand element is split exactly into three
+ *                          bf16 pieces (3 x 8 significant bits) on its way into LDS and a*b is accumulated in fp32 as six
+ *                          v_mfma_f32_32x32x16_bf16 terms (a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0; what is dropped is below the
+ *                          rounding of one fp32 product).  Error against fp64 <= that of the fp32 FMA chain (tests/test_gpu_f32x3.py);
+ *                          3x3 64->64 convolution 34 us instead of 49.  Only launches with k-contiguous operands (NT GEMMs, implicit-GEMM
+ *                          convolution forward / dgrad) have such a kernel; any other launch carrying the flag runs on fp32 MFMA.
+ *                          TATT_BF16 wins if both bits are set.
  * Replaces F.linear at
  * model/tsrn.py:213, :1083 (1x1 conv), model/transformer_v2.py:476,:480,:819,:829 (MHA in/out proj, FFN),
  * nn.GRU input projections (model/tsrn.py:1088, model/transformer_v2.py:218), stn_head.py:99-100. */

@@ -12,6 +12,7 @@
 // bits of the `flags` argument of the GEMM / convolution entry points (include/tatt_hip.h)
 #define TATT_RELU 1        // tatt_gemm, tatt_conv_fwd*: ReLU epilogue
 #define TATT_ACCUMULATE 1  // tatt_conv_wgrad, tatt_conv_skinny_fwd: add to the destination
+#define TATT_F32X3 4       // fp32 products from three bf16 pieces per operand (six v_mfma_f32_32x32x16_bf16 terms, fp32 accumulate); TATT_BF16 wins if both are set
 #define TATT_BF16 2        // operands rounded to bf16 (nearest-even) into v_mfma_f32_32x32x16_bf16, fp32 accumulate
 
 void tatt_set_error(const char* fmt, ...);

@@ -57,7 +57,7 @@ struct GemmArgs {
   long epi_ldx;
   const float *epi_stat, *epi_gamma, *epi_beta;  // EPI 2: stat [2][epi_C] (mean, invstd)
   int epi_act, epi_C;
-  int bf16;       // host only: operands rounded to bf16 on their way into the matrix core (TATT_BF16 flag of the entry point)
+  int bf16;       // host only, precision of the products: 0 fp32 MFMA, 1 operands rounded to bf16 (TATT_BF16), 2 three bf16 pieces per operand (TATT_F32X3)
   ConvGeom g;     // for OP_IM2COL / OP_CONVW / OP_IM2COL_N
   long w_sn, w_sci, w_stap, w_base;  // OP_CONVW: W[n*w_sn + ci*w_sci + w_base + tap*w_stap]
 };
@@ -163,11 +163,40 @@ __device__ __forceinline__ float epi_act_grad(float t, int act) {
   return 1.f;
 }
 
-template <int AOP, int BOP, bool FAST, bool BF16 = false, bool TAP9 = false, int EPI = 0>
-__global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
+// X3 (FAST, k-contiguous operands only; flag TATT_F32X3): fp32 products on the bf16 matrix core.  Every operand element is split
+// EXACTLY into three bf16 pieces x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = x - x0 - x1: 3 x 8 significant bits = the
+// 24 of an fp32) while it is staged into LDS (three bf16 planes per operand, 72 KB double-buffered), and a.b is accumulated in fp32
+// as the six products a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0 on v_mfma_f32_32x32x16_bf16; the three dropped ones (a1b2, a2b1,
+// a2b2) are <= 2^-24 |a.b| each, the rounding of one fp32 product.  12 bf16 MFMAs (8 passes each) per 32-k tile instead of 16 fp32
+// ones (16 passes each): 0.375 of the matrix time, and the bf16 pipe - unlike fp32 MFMA - runs beside the VALU.
+__device__ __forceinline__ void split3(const float4& v, uint2& p0, uint2& p1, uint2& p2) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned o0[2], o1[2], o2[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float a = x[2 * h], b = x[2 * h + 1];
+    const unsigned h0 = pack_bf16(a, b);
+    const float ra = a - __uint_as_float(h0 << 16), rb = b - __uint_as_float(h0 & 0xffff0000u);
+    const unsigned h1 = pack_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(h1 << 16), sb = rb - __uint_as_float(h1 & 0xffff0000u);
+    o0[h] = h0;
+    o1[h] = h1;
+    o2[h] = pack_bf16(sa, sb);
+  }
+  p0 = make_uint2(o0[0], o0[1]);
+  p1 = make_uint2(o1[0], o1[1]);
+  p2 = make_uint2(o2[0], o2[1]);
+}
+constexpr int X3_A_PLANE = BM * BK * 2, X3_B_PLANE = BN * BK * 2;    // bytes of one bf16 plane
+constexpr int X3_BUF = 3 * (X3_A_PLANE + X3_B_PLANE);                 // bytes of one buffer: A planes 0..2, B planes 0..2
+
+template <int AOP, int BOP, bool FAST, bool BF16, bool TAP9, int EPI, bool X3>
+__device__ __forceinline__ void gemm_body(const GemmArgs& a) {
   static_assert(FAST || !BF16, "the bf16 path exists for the FAST loaders only");
   static_assert(!TAP9 || (FAST && AOP == OP_IM2COL && BOP == OP_CONVW_P), "TAP9 is the 3x3 Cin=64 im2col specialisation");
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
+  static_assert(!X3 || (FAST && !BF16 && (AOP == OP_STRIDED || AOP == OP_IM2COL) && (BOP == OP_STRIDED || BOP == OP_CONVW_P)),
+                "X3 exists for FAST k-contiguous operands");
+  __shared__ __attribute__((aligned(16))) float lds[X3 ? 2 * X3_BUF / 4 : 2 * (A_FLOATS + B_FLOATS)];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -455,6 +484,25 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   const int st_swz = (kq ^ (r0 & 7)) * 4;  // rows r0 and r0 + 64 share r0 & 7
   const int st_swz16 = (((kq >> 1) ^ ((r0 >> 1) & 3)) << 4) + ((kq & 1) << 3);  // bf16 image: byte offset of k = 4 kq inside the row
   auto store_tiles = [&](int buf, const float4 (&ra)[2], const float4& rb) {
+    if constexpr (X3) {
+      char* Ab = reinterpret_cast<char*>(lds) + buf * X3_BUF;
+      char* Bb = Ab + 3 * X3_A_PLANE;
+      uint2 p0, p1, p2;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        split3(ra[j], p0, p1, p2);
+        char* d = Ab + (r0 + 64 * j) * 64 + st_swz16;
+        *reinterpret_cast<uint2*>(d) = p0;
+        *reinterpret_cast<uint2*>(d + X3_A_PLANE) = p1;
+        *reinterpret_cast<uint2*>(d + 2 * X3_A_PLANE) = p2;
+      }
+      split3(rb, p0, p1, p2);
+      char* d = Bb + r0 * 64 + st_swz16;
+      *reinterpret_cast<uint2*>(d) = p0;
+      *reinterpret_cast<uint2*>(d + X3_B_PLANE) = p1;
+      *reinterpret_cast<uint2*>(d + 2 * X3_B_PLANE) = p2;
+      return;
+    }
     float* As = lds + buf * (A_FLOATS + B_FLOATS);
     float* Bs = As + A_FLOATS;
     if constexpr (AOP == OP_ROWCONTIG || AOP == OP_IM2COL_M) {
@@ -484,6 +532,28 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
   auto compute = [&](int cur) {
+    if constexpr (X3) {
+      const char* Ab = reinterpret_cast<const char*>(lds) + cur * X3_BUF;
+      const char* Bb = Ab + 3 * X3_A_PLANE;
+      const int rowa = wm * 32 + li, rowb = wn * 32 + li;
+#pragma unroll
+      for (int g = 0; g < BK / 16; ++g) {
+        const char* pa = Ab + rowa * 64 + (((2 * g + lh) ^ ((rowa >> 1) & 3)) << 4);
+        const char* pb = Bb + rowb * 64 + (((2 * g + lh) ^ ((rowb >> 1) & 3)) << 4);
+        uint4 av[3], bv[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          av[p] = *reinterpret_cast<const uint4*>(pa + p * X3_A_PLANE);
+          bv[p] = *reinterpret_cast<const uint4*>(pb + p * X3_B_PLANE);
+        }
+#define X3_MFMA(i, j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc, 0, 0, 0)
+        X3_MFMA(2, 0); X3_MFMA(1, 1); X3_MFMA(0, 2);  // smallest terms first
+        X3_MFMA(1, 0); X3_MFMA(0, 1);
+        X3_MFMA(0, 0);
+#undef X3_MFMA
+      }
+      return;
+    }
     const float* As = lds + cur * (A_FLOATS + B_FLOATS);
     const float* Bs = As + A_FLOATS;
     if constexpr (BF16) {
@@ -723,6 +793,19 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
     }
   }
 }
+
+template <int AOP, int BOP, bool FAST, bool BF16 = false, bool TAP9 = false, int EPI = 0>
+__global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
+  gemm_body<AOP, BOP, FAST, BF16, TAP9, EPI, false>(a);
+}
+// the same launches with fp32 products made of three bf16 pieces per operand (flag TATT_F32X3, see gemm_body)
+template <int AOP, int BOP, bool TAP9 = false, int EPI = 0>
+__global__ __launch_bounds__(NTHR, 2) void gemm_x3_kernel(GemmArgs a) {
+  gemm_body<AOP, BOP, true, false, TAP9, EPI, true>(a);
+}
+template <int AOP, int BOP>
+constexpr bool x3_ok = (AOP == OP_STRIDED || AOP == OP_IM2COL) && (BOP == OP_STRIDED || BOP == OP_CONVW_P);
+inline int prec_of(int flags) { return (flags & TATT_BF16) ? 1 : (flags & TATT_F32X3) ? 2 : 0; }
 
 // sum slabs: dst[perm(i)] (+)= bias? + sum_z slab[z][i]
 // perm mode 0: identity over [M,N] with ldc; mode 1: conv weight (co, tap, ci) -> OIHW (co, ci, tap)
@@ -1021,15 +1104,24 @@ int launch(const GemmArgs& a, int batch, hipStream_t st) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch * a.splitk);
   if constexpr (AOP == OP_IM2COL && BOP == OP_CONVW_P) {  // 3x3, Cin = 64, packed weights, whole K in one pass: tap-unrolled loop
     if (g_tap9 && fast_ok<AOP, BOP>(a) && a.g.Cin == 64 && a.g.KH == 3 && a.g.KW == 3 && a.splitk == 1 && a.K == 576 && a.w_stap == 64) {
-      if (a.bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, true>), grid, dim3(NTHR), 0, st, a);
+      if (a.bf16 == 1) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, true>), grid, dim3(NTHR), 0, st, a);
+      else if (a.bf16 == 2) hipLaunchKernelGGL((gemm_x3_kernel<AOP, BOP, true>), grid, dim3(NTHR), 0, st, a);
       else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, false, true>), grid, dim3(NTHR), 0, st, a);
       TATT_LAUNCH_CHECK("gemm_kernel<tap9>");
       return TATT_OK;
     }
   }
   if (fast_ok<AOP, BOP>(a)) {
-    if (a.bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true>), grid, dim3(NTHR), 0, st, a);
-    else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true>), grid, dim3(NTHR), 0, st, a);
+    bool done = false;
+    if constexpr (x3_ok<AOP, BOP>) {
+      if (a.bf16 == 2) {
+        hipLaunchKernelGGL((gemm_x3_kernel<AOP, BOP>), grid, dim3(NTHR), 0, st, a);
+        done = true;
+      }
+    }
+    if (done) {
+    } else if (a.bf16 == 1) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true>), grid, dim3(NTHR), 0, st, a);
+    else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true>), grid, dim3(NTHR), 0, st, a);  // (TATT_F32X3 on operand layouts without an X3 kernel: exact fp32)
   } else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, false>), grid, dim3(NTHR), 0, st, a);
   TATT_LAUNCH_CHECK("gemm_kernel");
   return TATT_OK;
@@ -1045,13 +1137,21 @@ int launch_epi(const GemmArgs& a, hipStream_t st) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), 1);
   if constexpr (AOP == OP_IM2COL && BOP == OP_CONVW_P) {
     if (g_tap9 && a.g.Cin == 64 && a.g.KH == 3 && a.g.KW == 3 && a.K == 576 && a.w_stap == 64) {
-      if (a.bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, true, EPI>), grid, dim3(NTHR), 0, st, a);
+      if (a.bf16 == 1) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, true, EPI>), grid, dim3(NTHR), 0, st, a);
+      else if (a.bf16 == 2) hipLaunchKernelGGL((gemm_x3_kernel<AOP, BOP, true, EPI>), grid, dim3(NTHR), 0, st, a);
       else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, false, true, EPI>), grid, dim3(NTHR), 0, st, a);
       TATT_LAUNCH_CHECK("gemm_kernel<tap9, bn epilogue>");
       return TATT_OK;
     }
   }
-  if (a.bf16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, false, EPI>), grid, dim3(NTHR), 0, st, a);
+  if constexpr (x3_ok<AOP, BOP>) {
+    if (a.bf16 == 2) {
+      hipLaunchKernelGGL((gemm_x3_kernel<AOP, BOP, false, EPI>), grid, dim3(NTHR), 0, st, a);
+      TATT_LAUNCH_CHECK("gemm_x3_kernel<bn epilogue>");
+      return TATT_OK;
+    }
+  }
+  if (a.bf16 == 1) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, false, EPI>), grid, dim3(NTHR), 0, st, a);
   else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, false, false, EPI>), grid, dim3(NTHR), 0, st, a);
   TATT_LAUNCH_CHECK("gemm_kernel<bn epilogue>");
   return TATT_OK;
@@ -1106,7 +1206,7 @@ int tatt_gemm(const float* A, const float* B, float* C, const float* bias, int M
   a.sam = sam; a.sak = sak; a.sbn = sbn; a.sbk = sbk; a.ldc = ldc;
   a.sAb = sAb; a.sBb = sBb; a.sCb = sCb;
   a.splitk = splitk;
-  a.accumulate = accumulate; a.relu = relu; a.bf16 = (flags & TATT_BF16) != 0;
+  a.accumulate = accumulate; a.relu = relu; a.bf16 = prec_of(flags);
   a.kchunk = cdiv(cdiv(K, splitk), BK) * BK;
   if (a.kchunk == 0) a.kchunk = BK;
   if (splitk > 1) {  // slabs [batch][splitk][M][N]
@@ -1158,7 +1258,7 @@ int tatt_gemm_cat_bnbwd(const float* A, const float* A2, int ksplit, const float
   a.M = M; a.N = N; a.K = K;
   a.sam = sam; a.sak = 1; a.sbn = sbn; a.sbk = sbk; a.ldc = ldc;
   a.splitk = 1;
-  a.accumulate = accumulate; a.relu = flags & TATT_RELU; a.bf16 = (flags & TATT_BF16) != 0;
+  a.accumulate = accumulate; a.relu = flags & TATT_RELU; a.bf16 = prec_of(flags);
   a.kchunk = cdiv(K, BK) * BK;
   if (A2) { a.A2 = A2; a.ksplit = ksplit; }
   if (C2) { a.C2 = C2; a.nsplit = nsplit; a.ldc2 = ldc2; a.accumulate2 = accumulate2; }
@@ -1215,7 +1315,7 @@ int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, flo
   a.ldc = ldy;
   a.splitk = splitk;
   a.kchunk = cdiv(cdiv(a.K, splitk), BK) * BK;
-  a.accumulate = accumulate; a.relu = relu; a.bf16 = (flags & TATT_BF16) != 0;
+  a.accumulate = accumulate; a.relu = relu; a.bf16 = prec_of(flags);
   a.g = ConvGeom{H, W, Cin, KH, KW, KH / 2, KW / 2, (int)ldx};
   a.w_sn = w_sn; a.w_sci = w_sci; a.w_base = w_base; a.w_stap = w_stap;
   if (splitk > 1) {
@@ -1253,7 +1353,7 @@ int tatt_conv_fwd_bn(const float* X, const float* Wt, const float* bias, float* 
   a.ldc = ldy;
   a.splitk = 1;
   a.kchunk = cdiv(a.K, BK) * BK;
-  a.bf16 = (flags & TATT_BF16) != 0;
+  a.bf16 = prec_of(flags);
   a.g = ConvGeom{H, W, Cin, KH, KW, KH / 2, KW / 2, (int)ldx};
   a.w_sn = w_sn; a.w_sci = w_sci; a.w_base = w_base; a.w_stap = w_stap;
   a.epi_partial = partial; a.epi_C = Cout;
@@ -1297,7 +1397,7 @@ int tatt_conv_skinny_fwd(const float* X, const float* Wt, const float* bias, flo
   a.M = T * Cout; a.N = (int)P; a.K = Cin;
   a.sam = Cin; a.sak = 1; a.sbn = ldx; a.sbk = 1; a.ldc = P;
   a.splitk = 1;
-  a.bf16 = (flags & TATT_BF16) != 0;
+  a.bf16 = prec_of(flags);
   a.kchunk = cdiv(Cin, BK) * BK;
   int rc = launch<OP_STRIDED, OP_STRIDED>(a, 1, st);
   if (rc) return rc;
@@ -1330,7 +1430,7 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
   a.splitk = splitk;
   a.sCz = (long)a.M * a.N;
   a.kchunk = cdiv(cdiv(a.K, splitk), BK) * BK;
-  a.bf16 = (flags & TATT_BF16) != 0;
+  a.bf16 = prec_of(flags);
   a.g = ConvGeom{H, W, Cin, KH, KW, KH / 2, KW / 2, (int)ldx};
   int perm = 1, perm_c = Cin;
   if (Cout <= 16 && Cout % 4 == 0 && lddy % 4 == 0 && (((uintptr_t)dY) & 15) == 0) {

@@ -67,7 +67,9 @@ class Engine:
         # TATT_BF16 = operands rounded to bf16 into the MFMA, fp32 accumulate.  Set per forward call from module.matmul_precision
         # and kept in the call's context for its backward pass.  self.pf: the 3x3 convolutions of the trunk (SRBs, block7, the
         # up-sampling conv; forward, input and weight gradients) -- 85 % of the step's FLOPs, the launches that are matrix-core bound.
-        # self.pl: Linear / 1x1 / GRU-projection GEMMs: always 0.  With K = 64..192 they are bound by moving their fp32 tensors, so
+        # TATT_F32X3 (matmul_precision "f32x3", opt-in) = fp32 products from three bf16 pieces per operand: same accuracy as fp32 MFMA,
+        # so it goes on every launch that has such a kernel (pf and pl; `fp32=True` call sites stay on fp32 MFMA all the same).
+        # self.pl: Linear / 1x1 / GRU-projection GEMMs: 0 in fp32 and bf16 mode.  With K = 64..192 they are bound by moving their fp32 tensors, so
         # bf16 operands buy no time there, and measured at B=4 they carry most of the mode's error (output max-abs 1.4e-2 with them
         # in bf16, 6e-3 without).  The STN head, the TPS matrices, the recurrent positional encoding and the output convolution are
         # fp32 in both modes too: control points are scaled x64 into pixel coordinates by grid_sample, the RPE feeds every query,
@@ -592,9 +594,10 @@ class Engine:
         cfg = lambda site: self.dropcfg(site, seed, p)
         ctx = Ctx()
         prec = getattr(m, "matmul_precision", "fp32")
-        if prec not in ("fp32", "bf16"):
-            raise RuntimeError(f"matmul_precision must be 'fp32' or 'bf16', got {prec!r}")
-        self.pf = ctx["pf"] = 2 if prec == "bf16" else 0
+        if prec not in ("fp32", "bf16", "f32x3"):
+            raise RuntimeError(f"matmul_precision must be 'fp32', 'bf16' or 'f32x3', got {prec!r}")
+        self.pf = ctx["pf"] = {"fp32": 0, "bf16": 2, "f32x3": 4}[prec]
+        self.pl = ctx["pl"] = 4 if prec == "f32x3" else 0      # Linear / GRU-projection GEMMs: split products in that mode only
         ctx["meta"] = (B, training, seed, p)
         self.wpack = ctx["wpack"] = {} if wpack is None else wpack   # weights change every step: repacked per forward call
         R0 = B * H * W
@@ -803,7 +806,7 @@ class Engine:
             L.axpby(x, a, y, b, out, n, accumulate)
         L, m, P = self.L, self.m, self.P
         B, training, seed, p = ctx["meta"]
-        self.pf = ctx["pf"]
+        self.pf, self.pl = ctx["pf"], ctx.get("pl", 0)
         self.wpack = ctx["wpack"]
         cfg = lambda site: self.dropcfg(site, seed, p)
         H, W = 16, 64

@@ -57,19 +57,21 @@ def stn_scale(n):
     return 4.0 if n.startswith("stn_head.") else 1.0
 
 
-@pytest.mark.parametrize("rot", [False, True])
-def test_config2_and_config4_at_B64_vs_reference_golden(rot):
+@pytest.mark.parametrize("rot,prec", [(False, "fp32"), (True, "fp32"), (False, "f32x3")])
+def test_config2_and_config4_at_B64_vs_reference_golden(rot, prec):
     """BASELINE config 2 at its own size -- B = 64, train mode -- against goldens made by the real reference (fp32 and fp64 runs):
     output, every stage incl. the 64-step recurrent positional encoding (its chain length IS the batch size), control
     points, per-sample loss, all 231 gradient norms, twelve full gradients, BatchNorm statistics.  At this batch the train-mode
     BatchNorms are well conditioned, so this is the tight train-mode gradient pin: 1.5e-3 of the reference's fp64 run (STN head,
     whose ReLU / max-pool decisions and x64 pixel scaling amplify fp32 rounding, 6e-3).  rot = BASELINE config 4: the same
     with LR / HR pre-deformed by the reference's own rotation (model/__init__.py:4-30, +-10 degrees) through tatt_rotate_fwd,
-    asserting the rotated input, control points and the TPS-rectified image."""
+    asserting the rotated input, control points and the TPS-rectified image.  prec = "f32x3": the same pins, unchanged, for the
+    opt-in mode that forms the fp32 products of the trunk's 3x3 convolutions from three bf16 pieces per operand (TATT_F32X3)."""
     B, K = 64, 37
     g = load_golden(f"tsrn_K37_B64_{'rot_' if rot else ''}train.npz")
     m = build(K).train()
     m.dropout_p = 0.0
+    m.matmul_precision = prec
     hr, lr, tp = [t.cuda() for t in procgen.make_inputs(B, K, seed=0)]
     eng = m.engine()
     if rot:
@@ -209,12 +211,15 @@ def test_train_fwd_bwd_vs_oracle_with_stages(p):
     assert not bad, f"gradient mismatches vs oracle (name, err, fp32-oracle err, |ref|): {bad[:8]}"
 
 
-def test_eval_mode_backward_vs_oracle_fp64():
+@pytest.mark.parametrize("prec", ["fp32", "f32x3"])
+def test_eval_mode_backward_vs_oracle_fp64(prec):
     """The tight gradient pin: in eval mode (BatchNorm on running statistics, no STN) the network is well conditioned,
-    so every backward kernel of the trunk / TP interpreter / RPE recurrence must match the fp64 oracle to ~1e-4."""
+    so every backward kernel of the trunk / TP interpreter / RPE recurrence must match the fp64 oracle to ~1e-4 -- in the
+    default fp32-MFMA mode and, to the same bound, in the opt-in three-piece bf16 split mode (TATT_F32X3)."""
     B, K = 3, 37
     state = make_state(K, seed=3)
     m = build(K, seed=3).eval()
+    m.matmul_precision = prec
     hr, lr, tp = procgen.make_inputs(B, K, seed=7)
     sr, ctx = m.engine().forward(lr.cuda(), tp.cuda(), False, 0)
     L = m.engine().L
