@@ -163,7 +163,7 @@ __device__ __forceinline__ float epi_act_grad(float t, int act) {
   return 1.f;
 }
 
-// X3 (FAST, k-contiguous operands only; flag TATT_F32X3): fp32 products on the bf16 matrix core.  Every operand element is split
+// X3 (FAST loaders; flag TATT_F32X3): fp32 products on the bf16 matrix core.  Every operand element is split
 // EXACTLY into three bf16 pieces x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = x - x0 - x1: 3 x 8 significant bits = the
 // 24 of an fp32) while it is staged into LDS (three bf16 planes per operand, 72 KB double-buffered), and a.b is accumulated in fp32
 // as the six products a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0 on v_mfma_f32_32x32x16_bf16; the three dropped ones (a1b2, a2b1,
@@ -194,8 +194,7 @@ template <int AOP, int BOP, bool FAST, bool BF16, bool TAP9, int EPI, bool X3>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
   static_assert(FAST || !BF16, "the bf16 path exists for the FAST loaders only");
   static_assert(!TAP9 || (FAST && AOP == OP_IM2COL && BOP == OP_CONVW_P), "TAP9 is the 3x3 Cin=64 im2col specialisation");
-  static_assert(!X3 || (FAST && !BF16 && (AOP == OP_STRIDED || AOP == OP_IM2COL) && (BOP == OP_STRIDED || BOP == OP_CONVW_P)),
-                "X3 exists for FAST k-contiguous operands");
+  static_assert(!X3 || (FAST && !BF16 && BOP != OP_CONVW), "X3 exists for the FAST loaders");
   __shared__ __attribute__((aligned(16))) float lds[X3 ? 2 * X3_BUF / 4 : 2 * (A_FLOATS + B_FLOATS)];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -488,19 +487,50 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
       char* Ab = reinterpret_cast<char*>(lds) + buf * X3_BUF;
       char* Bb = Ab + 3 * X3_A_PLANE;
       uint2 p0, p1, p2;
+      if constexpr (AOP == OP_ROWCONTIG || AOP == OP_IM2COL_M) {
+        // row-contiguous source: a thread holds 4 rows at ONE k, the bf16 dwords need (k, k+1) of one row.  Lanes l and l ^ 32 hold
+        // k even / odd of the same rows: they swap half of their rows, then each splits (k, k+1) pairs of two rows.  Plane layout
+        // [k pair 16][row] dwords: conflict-free 8-byte stores here, four ds_read_b32 per fragment in compute().
+        const int h = lane >> 5;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        split3(ra[j], p0, p1, p2);
-        char* d = Ab + (r0 + 64 * j) * 64 + st_swz16;
-        *reinterpret_cast<uint2*>(d) = p0;
-        *reinterpret_cast<uint2*>(d + X3_A_PLANE) = p1;
-        *reinterpret_cast<uint2*>(d + 2 * X3_A_PLANE) = p2;
+        for (int j = 0; j < 2; ++j) {
+          const float4 my = ra[j];
+          const float s0 = h ? my.x : my.z, s1 = h ? my.y : my.w;
+          const float q0 = __shfl_xor(s0, 32, 64), q1 = __shfl_xor(s1, 32, 64);
+          const float4 v = h ? make_float4(q0, my.z, q1, my.w) : make_float4(my.x, q0, my.y, q1);
+          split3(v, p0, p1, p2);
+          char* d = Ab + (((wave + 8 * j) * BM + (tid & 31) * 4 + 2 * h) << 2);
+          *reinterpret_cast<uint2*>(d) = p0;
+          *reinterpret_cast<uint2*>(d + X3_A_PLANE) = p1;
+          *reinterpret_cast<uint2*>(d + 2 * X3_A_PLANE) = p2;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          split3(ra[j], p0, p1, p2);
+          char* d = Ab + (r0 + 64 * j) * 64 + st_swz16;
+          *reinterpret_cast<uint2*>(d) = p0;
+          *reinterpret_cast<uint2*>(d + X3_A_PLANE) = p1;
+          *reinterpret_cast<uint2*>(d + 2 * X3_A_PLANE) = p2;
+        }
       }
-      split3(rb, p0, p1, p2);
-      char* d = Bb + r0 * 64 + st_swz16;
-      *reinterpret_cast<uint2*>(d) = p0;
-      *reinterpret_cast<uint2*>(d + X3_B_PLANE) = p1;
-      *reinterpret_cast<uint2*>(d + 2 * X3_B_PLANE) = p2;
+      if constexpr (BOP == OP_ROWCONTIG || BOP == OP_IM2COL_N) {  // k = tid >> 4: lanes l and l ^ 16 hold k even / odd of the same 4 columns
+        const int h = (lane >> 4) & 1;
+        const float s0 = h ? rb.x : rb.z, s1 = h ? rb.y : rb.w;
+        const float q0 = __shfl_xor(s0, 16, 64), q1 = __shfl_xor(s1, 16, 64);
+        const float4 v = h ? make_float4(q0, rb.z, q1, rb.w) : make_float4(rb.x, q0, rb.y, q1);
+        split3(v, p0, p1, p2);
+        char* d = Bb + (((2 * wave + (lane >> 5)) * BN + (tid & 15) * 4 + 2 * h) << 2);
+        *reinterpret_cast<uint2*>(d) = p0;
+        *reinterpret_cast<uint2*>(d + X3_B_PLANE) = p1;
+        *reinterpret_cast<uint2*>(d + 2 * X3_B_PLANE) = p2;
+      } else {
+        split3(rb, p0, p1, p2);
+        char* d = Bb + r0 * 64 + st_swz16;
+        *reinterpret_cast<uint2*>(d) = p0;
+        *reinterpret_cast<uint2*>(d + X3_B_PLANE) = p1;
+        *reinterpret_cast<uint2*>(d + 2 * X3_B_PLANE) = p2;
+      }
       return;
     }
     float* As = lds + buf * (A_FLOATS + B_FLOATS);
@@ -538,13 +568,30 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
       const int rowa = wm * 32 + li, rowb = wn * 32 + li;
 #pragma unroll
       for (int g = 0; g < BK / 16; ++g) {
-        const char* pa = Ab + rowa * 64 + (((2 * g + lh) ^ ((rowa >> 1) & 3)) << 4);
-        const char* pb = Bb + rowb * 64 + (((2 * g + lh) ^ ((rowb >> 1) & 3)) << 4);
         uint4 av[3], bv[3];
+        if constexpr (AOP == OP_ROWCONTIG || AOP == OP_IM2COL_M) {
+          const char* pa = Ab + (((8 * g + 4 * lh) * BM + rowa) << 2);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          av[p] = *reinterpret_cast<const uint4*>(pa + p * X3_A_PLANE);
-          bv[p] = *reinterpret_cast<const uint4*>(pb + p * X3_B_PLANE);
+          for (int p = 0; p < 3; ++p) {
+            const unsigned* q = reinterpret_cast<const unsigned*>(pa + p * X3_A_PLANE);
+            av[p] = make_uint4(q[0], q[BM], q[2 * BM], q[3 * BM]);
+          }
+        } else {
+          const char* pa = Ab + rowa * 64 + (((2 * g + lh) ^ ((rowa >> 1) & 3)) << 4);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const uint4*>(pa + p * X3_A_PLANE);
+        }
+        if constexpr (BOP == OP_ROWCONTIG || BOP == OP_IM2COL_N) {
+          const char* pb = Bb + (((8 * g + 4 * lh) * BN + rowb) << 2);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const unsigned* q = reinterpret_cast<const unsigned*>(pb + p * X3_B_PLANE);
+            bv[p] = make_uint4(q[0], q[BN], q[2 * BN], q[3 * BN]);
+          }
+        } else {
+          const char* pb = Bb + rowb * 64 + (((2 * g + lh) ^ ((rowb >> 1) & 3)) << 4);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bv[p] = *reinterpret_cast<const uint4*>(pb + p * X3_B_PLANE);
         }
 #define X3_MFMA(i, j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc, 0, 0, 0)
         X3_MFMA(2, 0); X3_MFMA(1, 1); X3_MFMA(0, 2);  // smallest terms first
@@ -804,7 +851,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_x3_kernel(GemmArgs a) {
   gemm_body<AOP, BOP, true, false, TAP9, EPI, true>(a);
 }
 template <int AOP, int BOP>
-constexpr bool x3_ok = (AOP == OP_STRIDED || AOP == OP_IM2COL) && (BOP == OP_STRIDED || BOP == OP_CONVW_P);
+constexpr bool x3_ok = BOP != OP_CONVW;
 inline int prec_of(int flags) { return (flags & TATT_BF16) ? 1 : (flags & TATT_F32X3) ? 2 : 0; }
 
 // sum slabs: dst[perm(i)] (+)= bias? + sum_z slab[z][i]

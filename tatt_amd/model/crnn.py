@@ -61,9 +61,9 @@ class _Plan:
                 v = v.float().contiguous()
             out[k] = v
         prec = getattr(self.m, "matmul_precision", "fp32")
-        if prec not in ("fp32", "bf16"):
-            raise RuntimeError(f"matmul_precision must be 'fp32' or 'bf16', got {prec!r}")
-        self.pf = 2 if prec == "bf16" else 0          # TATT_BF16 flag of the GEMM / convolution entry points (per call)
+        if prec not in ("fp32", "bf16", "f32x3"):
+            raise RuntimeError(f"matmul_precision must be 'fp32', 'bf16' or 'f32x3', got {prec!r}")
+        self.pf = {"fp32": 0, "bf16": 2, "f32x3": 4}[prec]   # TATT_BF16 / TATT_F32X3 flag of the GEMM / convolution entry points (per call)
         self.dev = next(iter(out.values())).device
         if self.ws is None or self.ws.device != self.dev:
             self.ws = torch.empty(WS_FLOATS, device=self.dev)
@@ -329,7 +329,7 @@ class CRNN(nn.Module):
         self.cnn = cnn
         self.rnn = nn.Sequential(BidirectionalLSTM(512, nh, nh), BidirectionalLSTM(nh, nh, nclass))
         self.nclass = nclass
-        self.matmul_precision = "fp32"               # or "bf16": see tatt_amd.model.tsrn.TSRN_TL_TRANS.matmul_precision
+        self.matmul_precision = "fp32"               # or "bf16" / "f32x3": see tatt_amd.model.tsrn.TSRN_TL_TRANS.matmul_precision
         self._plan = None
 
     def plan(self):

@@ -21,13 +21,14 @@ def build(train):
     return m.cuda().train(train)
 
 
-@pytest.mark.parametrize("name,train", [("crnn_B2_eval", False), ("crnn_B3_train", True)])
-def test_crnn_forward_vs_reference_golden(name, train):
+@pytest.mark.parametrize("name,train,prec", [("crnn_B2_eval", False, "fp32"), ("crnn_B3_train", True, "fp32"), ("crnn_B3_train", True, "f32x3")])
+def test_crnn_forward_vs_reference_golden(name, train, prec):
     from tatt_amd.model.crnn import parse_crnn_data
     gold = np.load(os.path.join(GOLD, name + ".npz"))
     B = gold["hr/gray"].shape[0]
     hr, lr, _ = procgen.make_inputs(B, 37, seed=4)
     m = build(train)                                         # one module, hr then lr: as the golden generator ran it
+    m.matmul_precision = prec                                # "f32x3": the opt-in split-product mode, same tolerance
     for tag, img in (("hr", hr), ("lr", lr)):
         if not train:
             m = build(train)

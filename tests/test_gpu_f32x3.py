@@ -1,7 +1,7 @@
 """TATT_F32X3 (flag 4 of the GEMM / convolution entry points, model.matmul_precision = "f32x3"): fp32 products formed on the bf16
 matrix core from an exact three-piece bf16 split of every operand element (six terms, fp32 accumulate).  Opt-in; the default path
 multiplies on fp32 MFMA.  Bar: the same as the fp32 kernels' -- the result must be as close to the fp64 product of the UNROUNDED
-fp32 operands as the fp32 FMA chain is (rel-L2 <= 1e-6 and no worse than 1.5x the fp32 path's own error).  Model-level pins:
+fp32 operands as the fp32 FMA chain is (no worse than 1.5x the fp32 path's own error, which is 2e-7 .. 2e-6 with the length of the sum).  Model-level pins:
 tests/test_gpu_model.py runs the B=64 reference golden and the eval-mode gradient pin in this mode with unchanged tolerances."""
 import math
 
@@ -32,7 +32,7 @@ def err(got, ref):
 def both(run, ref, what):
     """run(flags) -> tensor comparable with ref (fp64)"""
     e32, e3 = err(run(0), ref), err(run(X3), ref)
-    assert e3 <= 1e-6 and e3 <= 1.5 * e32 + 2e-8, f"{what}: f32x3 rel-L2 {e3:.3e}, fp32 MFMA {e32:.3e}"
+    assert e3 <= 1.5 * e32 + 2e-8 and e3 <= 5e-6, f"{what}: f32x3 rel-L2 {e3:.3e}, fp32 MFMA {e32:.3e}"
     return e32, e3
 
 
@@ -47,6 +47,28 @@ def test_gemm_nt(M, N, K):
         L().gemm(Ad, Bd, out, bd, M, N, K, K, 1, K, 1, N, 1, 0, 0, 0, 0, fl, 1, None)
         return out
     both(run, ref, "gemm nt")
+    Bt, At = B_.t().contiguous().cuda(), A.t().contiguous().cuda()
+    ref0 = A.double() @ B_.double().t()
+    wsp = torch.empty(4 * M * N, device="cuda")
+
+    def nn(fl):                                               # B row-contiguous (the dX products)
+        out = torch.empty(M, N, device="cuda")
+        L().gemm(Ad, Bt, out, None, M, N, K, K, 1, 1, N, N, 1, 0, 0, 0, 0, fl, 1, None)
+        return out
+
+    def tn(fl):                                               # A row-contiguous, split-K (the dW products)
+        out = torch.empty(M, N, device="cuda")
+        L().gemm(At, Bd, out, None, M, N, K, 1, M, K, 1, N, 1, 0, 0, 0, 0, fl, 2, wsp)
+        return out
+
+    def tt(fl):
+        out = torch.empty(M, N, device="cuda")
+        L().gemm(At, Bt, out, None, M, N, K, 1, M, 1, N, N, 1, 0, 0, 0, 0, fl, 1, None)
+        return out
+    if M % 4 == 0 and N % 4 == 0:                             # the FAST loaders (and with them the split kernels) need 16-byte rows
+        both(nn, ref0, "gemm nn")
+        both(tn, ref0, "gemm tn split-K")
+        both(tt, ref0, "gemm tt")
     # values with a wide dynamic range inside one dot product: the split must stay exact piece by piece
     A2 = A * torch.exp(rnd(M, K, seed=5) * 4)
     ref2 = A2.double() @ B_.double().t()
@@ -81,6 +103,15 @@ def test_conv3x3_fwd_dgrad(B, H, W, Cin, Cout):
         return dx.permute(0, 3, 1, 2)
     both(fwd, y, "conv fwd")
     both(dgrad, gx, "conv dgrad")
+    wd64 = w.double().requires_grad_(True)
+    gw, = torch.autograd.grad(F.conv2d(x.double(), wd64, None, padding=1), (wd64,), dy.double())
+    wsp = torch.empty(8 << 20, device="cuda")
+
+    def wgrad(fl):
+        dW = torch.zeros(Cout, Cin, 3, 3, device="cuda")
+        L().conv_wgrad(xn, dyn, dW, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 4, wsp, 1 | fl)
+        return dW
+    both(wgrad, gw, "conv wgrad")
 
 
 @pytest.mark.parametrize("act", [0, 2])

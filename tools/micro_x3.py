@@ -50,3 +50,35 @@ for name, fl in (("fp32 MFMA", 0), ("f32x3", 4)):
     e1.synchronize()
     err = c.double() - refg
     print(f"gemm [65536,128]x[128,192]  {name:10s} max-abs {float(err.abs().max()):.3e} rel-L2 {float(err.norm() / refg.norm()):.3e}  {e0.elapsed_time(e1) / 50 * 1e3:6.1f} us")
+
+# weight gradient of the SRB convolution (row-contiguous operands: im2col(X)^T on M, dY on N) and a dX product (B row-contiguous)
+dy = torch.randn(B, H, W, Cout, device="cuda")
+wsp = torch.empty(16 << 20, device="cuda")
+gw = None
+for name, fl in (("fp32 MFMA", 0), ("f32x3", 4)):
+    dW = torch.zeros(Cout, Cin, 3, 3, device="cuda")
+    args = (x, dy, dW, B, H, W, Cin, Cout, 3, 3, Cin, Cout, 154, wsp, fl)
+    L.conv_wgrad(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        L.conv_wgrad(*args)
+    e1.record()
+    e1.synchronize()
+    if gw is None:
+        gw = dW.double()
+    print(f"conv wgrad 64->64 (+ slab reduce) {name:10s} rel-L2 vs fp32 path {float((dW.double() - gw).norm() / gw.norm()):.3e}  {e0.elapsed_time(e1) / 50 * 1e3:6.1f} us")
+g = torch.randn(M, N, device="cuda")
+refd = g.double() @ bw.double()
+for name, fl in (("fp32 MFMA", 0), ("f32x3", 4)):
+    dx = torch.zeros(M, K, device="cuda")
+    args = (g, bw, dx, None, M, K, N, N, 1, 1, K, K, 1, 0, 0, 0, 0, fl, 1, None)
+    L.gemm(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        L.gemm(*args)
+    e1.record()
+    e1.synchronize()
+    err = dx.double() - refd
+    print(f"gemm dX [65536,192]x[192,128] {name:10s} rel-L2 {float(err.norm() / refd.norm()):.3e}  {e0.elapsed_time(e1) / 50 * 1e3:6.1f} us")
