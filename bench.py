@@ -82,6 +82,13 @@ def conv_roofline(L, B, iters=10, bf16=False, x3=False):
         return {"bound": "hbm", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST,BF16> (3x3 conv fwd+dgrad, per-step mix of %d launches)" % len(calls),
                 "achieved": round(byts / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byts / dt / 8e12, 4), "traffic": None,
                 "launch_us": round(dt * 1e6, 2), "bytes_per_launch": byts, "tflops": round(ach, 2), "launches_per_step": len(calls)}
+    if x3:
+        # three-piece split: six bf16 MFMA terms per fp32 product -- executed matrix FLOPs = 6 x algorithmic, priced against the dense bf16 peak
+        return {"bound": "mfma", "kernel": "gemm_x3_kernel<OP_IM2COL,OP_CONVW_P,TAP9,EPI 0|1|2> (3x3 conv fwd+dgrad, fp32 products from three bf16 pieces "
+                "per operand, per-step mix of %d launches)" % len(calls), "achieved": round(6 * ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": round(6 * ach / 2500.0, 4), "traffic": None, "launch_us": round(dt * 1e6, 2), "flop_per_launch": fl,
+                "algorithmic_tflops": round(ach, 2), "algorithmic_frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "launches_per_step": len(calls)}
     return {"bound": "mfma", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST,TAP9,EPI 0|1|2> (3x3 conv fwd+dgrad with the step's epilogue variants, per-step mix of %d launches)" % len(calls),
             "measured": "standalone replay of the step's launch mix on an otherwise idle GPU, HIP events on the launch stream",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
@@ -210,7 +217,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "ms_per_step_median": round(per_step[len(per_step) // 2], 3), "ms_per_step_p90": round(per_step[int(0.9 * (len(per_step) - 1))], 3),
             "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bf16 else "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bf16 else "bf16x3->f32" if a.f32x3 else "f32", "data": "synthetic",
             "config": {"workload": ("whole reference iteration in %s: CRNN teacher + student priors, SR step%s, SemanticLoss, "
                                     "two-group Adam, K=%d" % (prec, " + TSC" if a.tsc else "", a.K)) if a.full else
                                    ("BASELINE config 3 step in %s (config 2 + TSC: second SR forward on the rotated input, "

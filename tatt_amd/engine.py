@@ -74,7 +74,8 @@ class Engine:
         # in bf16, 6e-3 without).  The STN head, the TPS matrices, the recurrent positional encoding and the output convolution are
         # fp32 in both modes too: control points are scaled x64 into pixel coordinates by grid_sample, the RPE feeds every query,
         # the output conv feeds the sigmoid directly -- their rounding error is amplified instead of averaged out.
-        self.pf, self.pl = 0, 0
+        # self.px: what a call site pinned with fp32=True gets -- 0 (fp32 MFMA) unless the mode itself has fp32 accuracy (f32x3).
+        self.pf, self.pl, self.px = 0, 0, 0
         self.wgrad_mode = os.environ.get("TATT_WGRAD_STREAM", "batch")
         if self.wgrad_mode not in ("batch", "off"):
             raise RuntimeError("TATT_WGRAD_STREAM must be 'batch' or 'off'")
@@ -206,19 +207,19 @@ class Engine:
 
     def linear(self, x, W, b, out, R, N, K, ldx=None, ldw=None, ldc=None, acc=0, relu=0, splitk=1, fp32=False):
         """out[R,N] (+)= x[R,K] @ W[N,K]^T + b   (splitk > 1 for the few-row, long-K products of the RPE)"""
-        self.L.gemm(x, W, out, b, R, N, K, ldx or K, 1, ldw or K, 1, ldc or N, 1, 0, 0, 0, acc, relu | (0 if fp32 else self.pl),
+        self.L.gemm(x, W, out, b, R, N, K, ldx or K, 1, ldw or K, 1, ldc or N, 1, 0, 0, 0, acc, relu | (self.px if fp32 else self.pl),
                     splitk, self.ws if splitk > 1 else None)
 
     def linear_dx(self, dy, W, dx, R, N, K, lddy=None, ldw=None, lddx=None, acc=0, splitk=1, fp32=False):
         """dx[R,K] (+)= dy[R,N] @ W[N,K]"""
         self._guard(dx)
-        self.L.gemm(dy, W, dx, None, R, K, N, lddy or N, 1, 1, ldw or K, lddx or K, 1, 0, 0, 0, acc, 0 if fp32 else self.pl, splitk,
+        self.L.gemm(dy, W, dx, None, R, K, N, lddy or N, 1, 1, ldw or K, lddx or K, 1, 0, 0, 0, acc, self.px if fp32 else self.pl, splitk,
                     self.ws if splitk > 1 else None)
 
     def linear_dw(self, dy, x, dW, R, N, K, lddy=None, ldx=None, lddw=None, fp32=False):
         """dW[N,K] += dy[R,N]^T @ x[R,K]  (always accumulates into the gradient buffer)"""
         sk = self._splitk(N, K, R)
-        fl = 0 if fp32 else self.pl
+        fl = self.px if fp32 else self.pl
         self._wgrad(lambda ws: self.L.gemm(dy, x, dW, None, N, K, R, 1, lddy or N, 1, ldx or K, lddw or K, 1, 0, 0, 0, 1, fl, sk,
                                            ws if sk > 1 else None), [dy], [x])
 
@@ -257,7 +258,7 @@ class Engine:
     def _skinny(self, x, W, b, out, B, H, Wd, Cin, Cout, k, wstr, acc, fp32=False):
         wsz = self.L.conv_skinny_workspace(B, H, Wd, Cin, Cout, k, k)
         z = self.new(wsz)                                      # planar Z [(tap,co)][pixel]: 340 MB for the output conv at B=64
-        self.L.conv_skinny_fwd(x, W, b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout, *wstr, acc | (0 if fp32 else self.pf), z)
+        self.L.conv_skinny_fwd(x, W, b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout, *wstr, acc | (self.px if fp32 else self.pf), z)
 
     def _prepack(self, use_stn):
         """Pack every convolution weight of the network for this forward call with ONE launch (tatt_conv_pack_w_group)."""
@@ -313,7 +314,7 @@ class Engine:
         if Cout in (4, 8, 16) and not relu:
             return self._skinny(x, W, b, out, B, H, Wd, Cin, Cout, k, (Cin * T, T, 0, 1), acc, fp32)
         self.L.conv_fwd_splitk(x, self._packed(W, Cout, Cin, k)[0], b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout,
-                               T * Cin, 1, 0, Cin, acc, relu | (0 if fp32 else self.pf), self._conv_splitk(B * H * Wd, Cout, T * Cin),
+                               T * Cin, 1, 0, Cin, acc, relu | (self.px if fp32 else self.pf), self._conv_splitk(B * H * Wd, Cout, T * Cin),
                                self.ws)
 
     def conv_dgrad(self, dy, W, dx, B, H, Wd, Cin, Cout, k, acc=0, fp32=False):
@@ -323,7 +324,7 @@ class Engine:
         if Cin in (4, 8, 16):
             return self._skinny(dy, W, None, dx, B, H, Wd, Cout, Cin, k, (T, Cin * T, T - 1, -1), acc, fp32)
         self.L.conv_fwd_splitk(dy, self._packed(W, Cout, Cin, k)[1], None, dx, B, H, Wd, Cout, Cin, k, k, Cout, Cin,
-                               T * Cout, 1, 0, Cout, acc, 0 if fp32 else self.pf, self._conv_splitk(B * H * Wd, Cin, T * Cout), self.ws)
+                               T * Cout, 1, 0, Cout, acc, self.px if fp32 else self.pf, self._conv_splitk(B * H * Wd, Cin, T * Cout), self.ws)
 
     def conv_wgrad(self, x, dy, dW, db, B, H, Wd, Cin, Cout, k, fp32=False, bias_grad=True):
         """bias_grad=False: the convolution feeds a training-mode BatchNorm, whose input gradient sums to zero over the rows for
@@ -341,7 +342,7 @@ class Engine:
         sk = max(1, min((B * H * Wd) // 256, -(-768 // tiles)))        # ~3 workgroups per CU (swept 256..1536: flat within 1 %)
         while sk > 1 and Cout * T * Cin * sk > WS_FLOATS:
             sk //= 2
-        fl = 1 | (0 if fp32 else self.pf)
+        fl = 1 | (self.px if fp32 else self.pf)
         self._wgrad(lambda ws: self.L.conv_wgrad(x, dy, dW, B, H, Wd, Cin, Cout, k, k, Cin, Cout, sk, ws, fl), [dy], [x])
         if bias_grad:
             self.colsum(dy, B * H * Wd, Cout, db)
@@ -597,7 +598,7 @@ class Engine:
         if prec not in ("fp32", "bf16", "f32x3"):
             raise RuntimeError(f"matmul_precision must be 'fp32', 'bf16' or 'f32x3', got {prec!r}")
         self.pf = ctx["pf"] = {"fp32": 0, "bf16": 2, "f32x3": 4}[prec]
-        self.pl = ctx["pl"] = 4 if prec == "f32x3" else 0      # Linear / GRU-projection GEMMs: split products in that mode only
+        self.pl = self.px = ctx["pl"] = 4 if prec == "f32x3" else 0   # Linear / GRU-projection GEMMs and fp32-pinned sites: split products in that mode only
         ctx["meta"] = (B, training, seed, p)
         self.wpack = ctx["wpack"] = {} if wpack is None else wpack   # weights change every step: repacked per forward call
         R0 = B * H * W
@@ -807,6 +808,7 @@ class Engine:
         L, m, P = self.L, self.m, self.P
         B, training, seed, p = ctx["meta"]
         self.pf, self.pl = ctx["pf"], ctx.get("pl", 0)
+        self.px = self.pl
         self.wpack = ctx["wpack"]
         cfg = lambda site: self.dropcfg(site, seed, p)
         H, W = 16, 64
