@@ -69,7 +69,7 @@ class Engine:
         # up-sampling conv; forward, input and weight gradients) -- 85 % of the step's FLOPs, the launches that are matrix-core bound.
         # TATT_F32X3 (matmul_precision "f32x3", opt-in) = fp32 products from three bf16 pieces per operand: same accuracy as fp32 MFMA,
         # so it goes on every launch that has such a kernel (pf and pl; `fp32=True` call sites stay on fp32 MFMA all the same).
-        # self.pl: Linear / 1x1 / GRU-projection GEMMs: 0 in fp32 and bf16 mode.  With K = 64..192 they are bound by moving their fp32 tensors, so
+        # self.pl: Linear / 1x1 / GRU-projection GEMMs: never TATT_BF16 (0 in fp32 mode, TATT_F32X3 in the other two).  With K = 64..192 they are bound by moving their fp32 tensors, so
         # bf16 operands buy no time there, and measured at B=4 they carry most of the mode's error (output max-abs 1.4e-2 with them
         # in bf16, 6e-3 without).  The STN head, the TPS matrices, the recurrent positional encoding and the output convolution are
         # fp32 in both modes too: control points are scaled x64 into pixel coordinates by grid_sample, the RPE feeds every query,
@@ -598,7 +598,9 @@ class Engine:
         if prec not in ("fp32", "bf16", "f32x3"):
             raise RuntimeError(f"matmul_precision must be 'fp32', 'bf16' or 'f32x3', got {prec!r}")
         self.pf = ctx["pf"] = {"fp32": 0, "bf16": 2, "f32x3": 4}[prec]
-        self.pl = self.px = ctx["pl"] = 4 if prec == "f32x3" else 0   # Linear / GRU-projection GEMMs and fp32-pinned sites: split products in that mode only
+        # Linear / GRU-projection GEMMs and the sites bf16 mode pins to fp32: split products (fp32 accuracy) in both non-default modes
+        # (bf16 mode: 6.77 -> 6.62 ms against fp32 MFMA on those launches, same error as before: 6.1e-3 max-abs at B=4)
+        self.pl = self.px = ctx["pl"] = 0 if prec == "fp32" else 4
         ctx["meta"] = (B, training, seed, p)
         self.wpack = ctx["wpack"] = {} if wpack is None else wpack   # weights change every step: repacked per forward call
         R0 = B * H * W
