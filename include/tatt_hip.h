@@ -151,7 +151,8 @@ int tatt_rpe_step_fwd(const float* gi, const float* whh_f, const float* whh_b, c
  * nn.GRU's time loop, model/transformer_v2.py:177,:215-221).  hstep [2][B+1][64][512] (h_0 set by the caller), gh_all [2][B][64][1536];
  * sync: device buffer of tatt_rpe_chain_sync_words(B) uint32, zeroed by the call on `stream`; sync[1] != 0 afterwards = a wait gave
  * up (results invalid).  Needs the GPU's CUs free enough to hold 32 workgroups of 512 threads per XCD at once; two calls that
- * share a sync buffer must not overlap. */
+ * share a sync buffer must not overlap.  Returns TATT_ERR_ARG when tatt_rpe_chain_supported() is 0. */
+size_t tatt_rpe_chain_supported(void);   /* 1: the current device can hold the chains (8 XCDs x >= 32 CUs, or fewer XCDs with room for their share); 0: use the step kernels */
 size_t tatt_rpe_chain_sync_words(int B);
 int tatt_rpe_chain_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* hstep, float* gh_all, float* qp, int B, long dir_stride_gh, long dir_stride_h, uint32_t* sync, hipStream_t stream);
 /* The B BPTT steps (s = B-1 .. 0) as ONE launch, same scheme; carry in/out and dgi_sum accumulated as by tatt_rpe_step_bwd; a sync buffer of its own. */

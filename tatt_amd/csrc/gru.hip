@@ -751,6 +751,17 @@ static int rpe_num_xcd() {
   return n;
 }
 
+// 1 if the chain kernels may be used on the current device: every XCD must be able to hold its chains' 32 workgroups each on a CU of
+// their own (MI355X in its default partition mode: 8 XCDs x 32 CUs, one chain per XCD); else 0 -- use tatt_rpe_step_fwd / _bwd.
+size_t tatt_rpe_chain_supported(void) {
+  int dev = 0, n = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1 || n > 8)
+    return 0;
+  const int chains_per_xcd = (8 + n - 1) / n;
+  return (size_t)(chains_per_xcd * 32 <= cus / n ? 1 : 0);
+}
+
 size_t tatt_rpe_chain_sync_words(int B) { (void)B; return (size_t)RPE_SYNC_WORDS; }
 
 // All B steps of tatt_rpe_step_fwd in one launch (see rpe_chain_fwd).  hstep [2][B+1][64][512] with h_0 = hstep[:, 0] set by the caller,
@@ -760,6 +771,7 @@ int tatt_rpe_chain_fwd(const float* gi, const float* whh_f, const float* whh_b, 
                        float* gh_all, float* qp, int B, long dir_stride_gh, long dir_stride_h, uint32_t* sync, hipStream_t st) {
   TATT_CHECK_ARG(gi && whh_f && whh_b && bhh_f && bhh_b && hstep && gh_all && qp && sync && B > 0 && B <= 4096, "tatt_rpe_chain_fwd: bad arguments");
   TATT_CHECK_ARG(2L * (B + 1) * RW * RH * 4 < (1L << 31) && dir_stride_h >= (long)(B + 1) * RW * RH, "tatt_rpe_chain_fwd: hstep too large / bad stride");
+  TATT_CHECK_ARG(tatt_rpe_chain_supported(), "tatt_rpe_chain_fwd: this device cannot hold the chains (tatt_rpe_chain_supported() == 0): use the per-step kernels");
   const int nxcd = rpe_num_xcd();
   if (hipMemsetAsync(sync, 0, tatt_rpe_chain_sync_words(B) * 4, st) != hipSuccess) {
     tatt_set_error("tatt_rpe_chain_fwd: hipMemsetAsync failed");
@@ -778,6 +790,7 @@ int tatt_rpe_chain_bwd(const float* gi, const float* gh_all, const float* bhh_f,
                        uint32_t* sync, hipStream_t st) {
   TATT_CHECK_ARG(gi && gh_all && bhh_f && bhh_b && hstep && dqp && carry && dgh_all && dgi_sum && whhT && sync && B > 0 && B <= 4096,
                  "tatt_rpe_chain_bwd: bad arguments");
+  TATT_CHECK_ARG(tatt_rpe_chain_supported(), "tatt_rpe_chain_bwd: this device cannot hold the chains (tatt_rpe_chain_supported() == 0): use the per-step kernels");
   const int nxcd = rpe_num_xcd();
   if (hipMemsetAsync(sync, 0, tatt_rpe_chain_sync_words(B) * 4, st) != hipSuccess) {
     tatt_set_error("tatt_rpe_chain_bwd: hipMemsetAsync failed");

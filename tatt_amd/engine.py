@@ -76,6 +76,7 @@ class Engine:
         # the output conv feeds the sigmoid directly -- their rounding error is amplified instead of averaged out.
         # self.px: what a call site pinned with fp32=True gets -- 0 (fp32 MFMA) unless the mode itself has fp32 accuracy (f32x3).
         self.pf, self.pl, self.px = 0, 0, 0
+        self._rpe_chain_ok = None
         self.wgrad_mode = os.environ.get("TATT_WGRAD_STREAM", "batch")
         if self.wgrad_mode not in ("batch", "off"):
             raise RuntimeError("TATT_WGRAD_STREAM must be 'batch' or 'off'")
@@ -167,6 +168,13 @@ class Engine:
         """Call before the main stream writes `t` in place: if a pending weight-gradient kernel still reads it, join first."""
         if self._w_pending and t is not None and t.untyped_storage().data_ptr() in self._w_pending:
             self._w_join()
+
+    def rpe_chain(self):
+        """Single-launch RPE chains: on unless TATT_RPE_CHAIN=0 or the device cannot hold them (tatt_rpe_chain_supported: another
+        partition mode, fewer CUs per XCD) -- then the recurrence runs as one launch per step."""
+        if self._rpe_chain_ok is None:
+            self._rpe_chain_ok = RPE_CHAIN and bool(self.L.rpe_chain_supported())
+        return self._rpe_chain_ok
 
     def check_rpe_chain(self):
         """Raise if a single-launch RPE chain (tatt_rpe_chain_fwd / _bwd) of the last pass reported a reader that gave up waiting
@@ -638,7 +646,7 @@ class Engine:
             dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                if RPE_CHAIN:   # the whole chain as one launch of persistent workgroups (tatt_rpe_chain_fwd)
+                if self.rpe_chain():   # the whole chain as one launch of persistent workgroups (tatt_rpe_chain_fwd)
                     self._rpe_sync = torch.empty(L.rpe_chain_sync_words(B), device=self.dev, dtype=torch.int32)
                     L.rpe_chain_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep, gh_all, qp, B, dsg, dsh,
                                     self._rpe_sync)
@@ -908,7 +916,7 @@ class Engine:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 L.rpe_whh_transpose(whh_f, whh_b, whhT)
-                if RPE_CHAIN:   # the whole BPTT chain as one launch of persistent workgroups (tatt_rpe_chain_bwd)
+                if self.rpe_chain():   # the whole BPTT chain as one launch of persistent workgroups (tatt_rpe_chain_bwd)
                     self._rpe_sync_b = torch.empty(L.rpe_chain_sync_words(B), device=self.dev, dtype=torch.int32)
                     L.rpe_chain_bwd(gi, gh_all, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep, dqp, carry, dgh_all, dgi_sum, whhT,
                                     B, dsg, dsh, self._rpe_sync_b)

@@ -334,6 +334,8 @@ def test_rpe_fused_steps_vs_torch_gru(B, chain):
     bf, bb = W["bias_hh_l0"], W["bias_hh_l0_reverse"]
     sync = torch.full((L().rpe_chain_sync_words(B),), 7, device="cuda", dtype=torch.int32)      # the call zeroes it itself
     if chain:
+        assert L().rpe_chain_supported() == 1, "an MI355X in its default partition mode holds the chains (8 XCDs x 32 CUs)"
+    if chain:
         L().rpe_chain_fwd(gi, W["weight_hh_l0"], W["weight_hh_l0_reverse"], bf, bb, hstep, gh_all, qp, B, dsg, dsh, sync)
         assert int(sync[1]) == 0, "a reader of the forward chain gave up waiting"
     else:
