@@ -77,6 +77,7 @@ class Engine:
         # self.px: what a call site pinned with fp32=True gets -- 0 (fp32 MFMA) unless the mode itself has fp32 accuracy (f32x3).
         self.pf, self.pl, self.px = 0, 0, 0
         self._rpe_chain_ok = None
+        self.ws_side = None
         self.wgrad_mode = os.environ.get("TATT_WGRAD_STREAM", "batch")
         if self.wgrad_mode not in ("batch", "off"):
             raise RuntimeError("TATT_WGRAD_STREAM must be 'batch' or 'off'")
@@ -213,10 +214,11 @@ class Engine:
             s //= 2
         return max(1, s)
 
-    def linear(self, x, W, b, out, R, N, K, ldx=None, ldw=None, ldc=None, acc=0, relu=0, splitk=1, fp32=False):
-        """out[R,N] (+)= x[R,K] @ W[N,K]^T + b   (splitk > 1 for the few-row, long-K products of the RPE)"""
+    def linear(self, x, W, b, out, R, N, K, ldx=None, ldw=None, ldc=None, acc=0, relu=0, splitk=1, fp32=False, ws=None):
+        """out[R,N] (+)= x[R,K] @ W[N,K]^T + b   (splitk > 1 for the few-row, long-K products of the RPE; ws: the split-K workspace
+        when the call runs on a stream beside the main one, which owns self.ws)"""
         self.L.gemm(x, W, out, b, R, N, K, ldx or K, 1, ldw or K, 1, ldc or N, 1, 0, 0, 0, acc, relu | (self.px if fp32 else self.pl),
-                    splitk, self.ws if splitk > 1 else None)
+                    splitk, (ws if ws is not None else self.ws) if splitk > 1 else None)
 
     def linear_dx(self, dy, W, dx, R, N, K, lddy=None, ldw=None, lddx=None, acc=0, splitk=1, fp32=False):
         """dx[R,K] (+)= dy[R,N] @ W[N,K]"""
@@ -614,8 +616,6 @@ class Engine:
         R0 = B * H * W
         use_stn = bool(m.stn and training)
         ctx["x"] = x
-        self._prepack(use_stn)
-        self._gru_fold()
 
         # ---- recurrent positional encoding (model/transformer_v2.py:215-221): GRU over the batch axis, identical input at
         # every step.  It depends on weights only and is a chain of B dependent, latency-bound launches, so it is forked
@@ -634,18 +634,24 @@ class Engine:
             ctx["rpe_owner"] = rpe_from
             rpe_from["rpe_lent"] = True
         else:
+            # The whole strand -- input gather, the two time-invariant input projections (split-K into a workspace of the strand's
+            # own), h_0 = 0 and the chain -- is forked before anything else of the pass is issued: it reads weights only, and with
+            # its 100 us of small launches on the main stream the STN head / block1 started that much later.
             xg = self.new(64, 1024)
-            L.rpe_gather_x(P[ig + "init_factor.weight"], xg)
             gi = self.new(2, 64, 1536)
-            self.linear(xg, P[g + "weight_ih_l0"], P[g + "bias_ih_l0"], gi[0], 64, 1536, 1024, splitk=8, fp32=True)
-            self.linear(xg, P[g + "weight_ih_l0_reverse"], P[g + "bias_ih_l0_reverse"], gi[1], 64, 1536, 1024, splitk=8, fp32=True)
-            hstep = self.zeros(2, B + 1, 64, 512)
             gh_all = self.new(2, B, 64, 1536)
             qp = self.new(R0, 64)
             whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
             dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
+            if self.ws_side is None or self.ws_side.device != self.dev:
+                self.ws_side = torch.empty(8 * 64 * 1536, device=self.dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                L.rpe_gather_x(P[ig + "init_factor.weight"], xg)
+                self.linear(xg, P[g + "weight_ih_l0"], P[g + "bias_ih_l0"], gi[0], 64, 1536, 1024, splitk=8, fp32=True, ws=self.ws_side)
+                self.linear(xg, P[g + "weight_ih_l0_reverse"], P[g + "bias_ih_l0_reverse"], gi[1], 64, 1536, 1024, splitk=8, fp32=True,
+                            ws=self.ws_side)
+                hstep = self.zeros(2, B + 1, 64, 512)
                 if self.rpe_chain():   # the whole chain as one launch of persistent workgroups (tatt_rpe_chain_fwd)
                     self._rpe_sync = torch.empty(L.rpe_chain_sync_words(B), device=self.dev, dtype=torch.int32)
                     L.rpe_chain_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep, gh_all, qp, B, dsg, dsh,
@@ -682,6 +688,11 @@ class Engine:
             mem, v2e = self.ln_fwd(e + "norm2.", s1, f_e, cfg("enc_drop2"), Rt)
             kin = self.new(Rt, 64)
             L.axpby(mem, 1.0, pos, 1.0, kin, Rt * 64, 0)
+
+        # per-step weight packs of the main strand (conv weights in MFMA order, 1x1 conv folded into the GRU projections): issued
+        # after the two forks, which need neither
+        self._prepack(use_stn)
+        self._gru_fold()
 
         # ---- STN head + TPS rectification (model/tsrn.py:655-657) ------------------------------------------
         if use_stn:
