@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--f32x3", action="store_true", help="fp32 products of the trunk convolutions computed on the bf16 matrix core from "
                                                         "three bf16 pieces per operand (six terms, fp32 accumulate; error at the level "
                                                         "of the fp32 FMA chain): opt-in, the default metric uses fp32 MFMA")
+    ap.add_argument("--no-stn", action="store_true", help="experiment: the network without its STN head / TPS rectification (not a BASELINE config)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,7 +154,7 @@ def main():
     from tatt_amd.trainer import SRTrainer
 
     torch.manual_seed(123)
-    model = TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32,
+    model = TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=not a.no_stn, mask=True, srb_nums=5, hidden_units=32,
                           text_embedding=a.K)
     state_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.cuda().train()
@@ -223,7 +224,7 @@ def main():
                                    ("BASELINE config 3 step in %s (config 2 + TSC: second SR forward on the rotated input, "
                                     "TRI_SSIM x10), K=%d" % (prec, a.K)) if a.tsc else
                                    "BASELINE config 2: TSRN_TL_TRANS(STN, K=%d) single training step %s, pixel+gradient loss, "
-                                   "clip 0.25 + Adam, frozen text prior" % (a.K, prec),
+                                   "clip 0.25 + Adam, frozen text prior%s" % (a.K, prec, " -- EXPERIMENT: STN head removed, not config 2" if a.no_stn else ""),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "lr_shape": [4, 16, 64], "hr_shape": [4, 32, 128],
                        "parallelism": f"dp{world}", "hip_graph": bool(trainer.use_graph), "loss": round(loss, 4),
                        **({"precision": "bf16 MFMA operands (round-to-nearest-even), fp32 accumulate; tensors in HBM, recurrences, "
