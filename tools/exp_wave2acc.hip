@@ -160,6 +160,85 @@ void run64(const float* X, float* d, int blocks, bool SHORT) {
   double fl = (double)blocks * ntiles * 2.0 * 64 * BN * BK;
   printf("%-28s %-10s blocks=%d: %.3f ms  %.1f TFLOP/s  (%.1f us per 18-tile launch)\n", "64x64 tile, 4 waves", SHORT ? "20x18" : "1x360", blocks, ms, fl / ms * 1e-9, ms * 50);
 }
+// 256x64 tile, SIXTEEN waves x one 32x32 accumulator, one workgroup per CU: four waves per SIMD that advance in lockstep (one barrier
+// per tile) -- two co-resident 8-wave workgroups do not: the older one gets the matrix pipe first, ends at 33 us and leaves the
+// younger one alone (two waves per SIMD cannot keep the pipe full) until 44 us (per-workgroup timestamps of the product kernel)
+__global__ __launch_bounds__(1024, 1) void k16(const float* __restrict__ X, float* out, int ntiles) {
+  constexpr int M2 = 256;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (M2 + BN) * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 7, wn = wave >> 3;
+  const int kq = tid & 7, r0 = tid >> 3;  // 128 rows per pass
+  for (int i = tid; i < 2 * (M2 + BN) * BK; i += 1024) lds[i] = i * 1e-6f;
+  __syncthreads();
+  f32x16 acc;
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float4 r[2][3];
+  for (int s = 0; s < 2; ++s)
+    for (int j = 0; j < 3; ++j) r[s][j] = make_float4(1.f, 2.f, 3.f, 4.f);
+  const float* xp = X + ((long)blockIdx.x * 384 + r0) * 64 + kq * 4;
+  const bool hasb = r0 < 64;  // wave-uniform: waves 0..7 also stage the B tile
+  auto gload = [&](int t, float4 (&rr)[3]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) rr[j] = *reinterpret_cast<const float4*>(xp + (long)j * 128 * 64 + (t & 1) * 32);
+    if (hasb) rr[2] = *reinterpret_cast<const float4*>(xp + (long)2 * 128 * 64 + (t & 1) * 32);
+  };
+  auto dswrite = [&](int buf, const float4 (&rr)[3]) {
+    float* b = lds + buf * (M2 + BN) * BK;
+    const int sw = (kq ^ (r0 & 7)) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(b + (r0 + 128 * j) * BK + sw) = rr[j];
+    if (hasb) *reinterpret_cast<float4*>(b + (r0 + 256) * BK + sw) = rr[2];
+  };
+  auto compute = [&](int buf) {
+    const float* As = lds + buf * (M2 + BN) * BK;
+    const float* Bs = As + M2 * BK;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      const int sw = ((2 * kg + lh) ^ (li & 7)) << 2;
+      float4 a = *reinterpret_cast<const float4*>(As + (wm * 32 + li) * BK + sw);
+      float4 b = *reinterpret_cast<const float4*>(Bs + (wn * 32 + li) * BK + sw);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+  };
+  gload(1, r[1]);
+  gload(2, r[0]);
+  for (int t = 0; t < ntiles; t += 2) {
+    dswrite(1, r[1]);
+    gload(t + 3, r[1]);
+    compute(0);
+    __syncthreads();
+    dswrite(0, r[0]);
+    gload(t + 4, r[0]);
+    compute(1);
+    __syncthreads();
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += acc[i];
+  out[blockIdx.x * 1024 + tid] = s + r[0][0].x + r[1][1].y;
+}
+void run16(const float* X, float* d, int blocks, bool SHORT) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const int ntiles = 18 * 20;
+  hipLaunchKernelGGL(k16, dim3(blocks), dim3(1024), 0, 0, X, d, 18);
+  (void)hipEventRecord(e0);
+  if (SHORT) {
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k16, dim3(blocks), dim3(1024), 0, 0, X, d, 18);
+  } else {
+    hipLaunchKernelGGL(k16, dim3(blocks), dim3(1024), 0, 0, X, d, ntiles);
+  }
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  double fl = (double)blocks * ntiles * 2.0 * 256 * BN * BK;
+  printf("%-28s %-10s blocks=%d: %.3f ms  %.1f TFLOP/s  (%.1f us per 18-tile launch)\n", "256x64 tile, 16 waves", SHORT ? "20x18" : "1x360", blocks, ms, fl / ms * 1e-9, ms * 50);
+}
 int main() {
   float *d, *X;
   (void)hipMalloc(&d, 2048 * 512 * 4);
@@ -170,6 +249,10 @@ int main() {
       run<8>("8 waves x 1 acc", X, d, blocks, s);
       run<4>("4 waves x 2 acc", X, d, blocks, s);
     }
+  }
+  for (int blocks : {256, 512}) {
+    run16(X, d, blocks, false);
+    run16(X, d, blocks, true);
   }
   for (int blocks : {1024, 2048}) {
     run64(X, d, blocks, false);
