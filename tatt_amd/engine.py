@@ -584,7 +584,63 @@ class Engine:
         return dres
 
     # ================================================================================================================
+    # ---- mask=False (three image channels, reference --mask off: model/tsrn.py:586, interfaces/base.py:179-181) ------------------
+    # The kernels are built for four channels.  A three-channel network is the four-channel one whose extra input channel is zero
+    # and whose weights touching that channel are zero: block1 and the STN head's first convolution get a zero input-channel slice,
+    # the output convolution a zero fourth filter + bias (its output, sigmoid(0), is dropped).  The padded tensors are made per call
+    # from the module's parameters; their gradients are computed into padded temporaries and the live slices added to G.
+    def _pad3_names(self):
+        k8 = f"block{self.m.srb_nums + 3}.1."
+        names = {"block1.0.weight": 1, k8 + "weight": 0, k8 + "bias": 0}
+        if self.m.stn:
+            names["stn_head.stn_convnet.0.0.weight"] = 1
+        return names
+
     def forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True, wpack=None, tp_ready=None, rpe_from=None):
+        if getattr(self.m, "in_planes", 4) == 4:
+            return self._forward(x, text_emb, training, seed, p_drop, want_ctx, wpack, tp_ready, rpe_from)
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 16, 64):
+            raise RuntimeError(f"expected LR input [B,3,16,64] (mask=False), got {tuple(x.shape)}")
+        if wpack is not None or rpe_from is not None:
+            raise NotImplementedError("mask=False: the two-pass (TSC) step is not wired up")
+        self.refresh()
+        orig = self.P
+        padded = dict(orig)
+        for n, dim in self._pad3_names().items():
+            t = orig[n]
+            shape = list(t.shape)
+            shape[dim] = 1
+            padded[n] = torch.cat([t, t.new_zeros(shape)], dim).contiguous()
+        x4 = torch.cat([x.detach().float(), x.new_zeros(x.shape[0], 1, 16, 64, dtype=torch.float32)], 1).contiguous()
+        self.P = padded
+        try:
+            sr4, ctx = self._forward(x4, text_emb, training, seed, p_drop, want_ctx, None, tp_ready, None)
+        finally:
+            self.P = orig
+        ctx["pad3"] = padded
+        return sr4[:, :3].contiguous(), ctx
+
+    def backward(self, ctx, dsr, G, on_stage=None):
+        padded = ctx.get("pad3")
+        if padded is None:
+            return self._backward(ctx, dsr, G, on_stage)
+        if on_stage is not None:
+            raise NotImplementedError("mask=False: bucketed data-parallel training is not wired up")
+        orig = self.P
+        G4 = dict(G)
+        names = self._pad3_names()
+        for n in names:
+            G4[n] = torch.zeros_like(padded[n])
+        dsr4 = torch.cat([dsr.float(), dsr.new_zeros(dsr.shape[0], 1, *dsr.shape[2:], dtype=torch.float32)], 1).contiguous()
+        self.P = padded
+        try:
+            self._backward(ctx, dsr4, G4, None)
+        finally:
+            self.P = orig
+        for n, dim in names.items():
+            G[n] += G4[n].narrow(dim, 0, 3)
+
+    def _forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True, wpack=None, tp_ready=None, rpe_from=None):
         """tp_ready: optional torch.cuda.Event after which `text_emb` may be read (the prior generator may still be running on
         another stream while the STN head, block1 and the RPE chain -- which do not need the prior -- are under way).
         wpack: the packed conv weights of an earlier forward call on the SAME weights (the TSC step runs the network
@@ -807,7 +863,7 @@ class Engine:
         return sr, ctx
 
     # ================================================================================================================
-    def backward(self, ctx, dsr, G, on_stage=None):
+    def _backward(self, ctx, dsr, G, on_stage=None):
         """Accumulates parameter gradients of one forward call into G (dict name -> fp32 tensor).
         on_stage(name) is called when a gradient bucket is complete ("tail", "srbs", then "head" and "infogen" together at the end):
         the data-parallel trainer starts that bucket's all-reduce there, overlapping the rest of the pass."""

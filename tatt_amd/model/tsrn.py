@@ -87,9 +87,9 @@ class TSRN_TL_TRANS(nn.Module):
         assert math.log(scale_factor, 2) % 1 == 0
         # what the hand-written kernels are built for (the only configuration the reference constructs,
         # interfaces/base.py:179-181); fail loudly instead of silently computing something else
-        if not (scale_factor == 2 and hidden_units == 32 and out_text_channels == 64 and mask
-                and (height, width) == (32, 128)):
-            raise NotImplementedError("tatt_amd kernels are specialised for scale 2, 4-channel 16x64 -> 32x128, hidden_units 32")
+        # (mask=False, three channels: runs on the same kernels through zero-padded fourth channels, tatt_amd/engine.py)
+        if not (scale_factor == 2 and hidden_units == 32 and out_text_channels == 64 and (height, width) == (32, 128)):
+            raise NotImplementedError("tatt_amd kernels are specialised for scale 2, 16x64 -> 32x128, hidden_units 32")
         self.block1 = nn.Sequential(nn.Conv2d(in_planes, 2 * hidden_units, kernel_size=9, padding=4), nn.PReLU())
         self.srb_nums = srb_nums
         for i in range(srb_nums):

@@ -91,6 +91,9 @@ class SRTrainer:
     def __init__(self, model, lr=1e-3, betas=(0.5, 0.999), eps=1e-8, max_norm=0.25, loss_weight=(1.0, 1e-4),
                  use_graph=False, distributed=None, tsc=False, tssim_rotation_degree=10.0, training_stablize=False):
         self.model, self.L = model, lib()
+        if getattr(model, "in_planes", 4) != 4:
+            raise NotImplementedError("SRTrainer: the fused training step is wired for mask=True (four channels); a mask=False model "
+                                      "trains through its autograd interface (model(lr, prior) -> loss.backward() -> torch.optim)")
         self.lr, self.betas, self.eps, self.max_norm, self.loss_weight = lr, betas, eps, max_norm, loss_weight
         # data parallel whenever a process group exists (a 1-rank group takes the same broadcast / all-reduce path, which is
         # how the RCCL plumbing is tested on a single GPU)
