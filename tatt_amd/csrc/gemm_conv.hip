@@ -190,12 +190,24 @@ __device__ __forceinline__ void split3(const float4& v, uint2& p0, uint2& p1, ui
 constexpr int X3_A_PLANE = BM * BK * 2, X3_B_PLANE = BN * BK * 2;    // bytes of one bf16 plane
 constexpr int X3_BUF = 3 * (X3_A_PLANE + X3_B_PLANE);                 // bytes of one buffer: A planes 0..2, B planes 0..2
 
-template <int AOP, int BOP, bool FAST, bool BF16, bool TAP9, int EPI, bool X3>
+// HALO (TAP9 launches on W = 64 maps in bf16 / split-product precision): the north star's "LDS-staged halo tile".  A workgroup's
+// 128 output pixels are two image rows; their 3x3 neighbourhood is four rows x 66 columns.  Instead of fetching (and, for X3,
+// splitting) every input element once per tap -- nine times -- the halo of 32 input channels is staged ONCE into LDS as bf16
+// planes (rows = halo pixels, the bf16 image format of the BF16 path), and the nine taps read their A fragments from it at
+// shifted pixel indices; only the weight tiles stream through the double buffer.  K runs channel-half major (32 channels x 9
+// taps, then the other 32): 50.7 KB of halo + 24 KB of weight tiles for X3, two workgroups per CU.  With fp32 MFMA the per-tap
+// re-reads are hidden behind the matrix pipe (profiles/r02_conv_knockout.md); with the bf16 pipe they and the split are the time.
+constexpr int HALO_Q = 4 * 66;            // halo pixels of a 2 x 64 pixel tile
+constexpr int HALO_PLANE = HALO_Q * 64;   // bytes of one bf16 plane (32 channels)
+
+template <int AOP, int BOP, bool FAST, bool BF16, bool TAP9, int EPI, bool X3, bool HALO = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
+  static_assert(!HALO || (TAP9 && (BF16 || X3)), "HALO is a variant of the TAP9 launches in bf16 / split-product precision");
   static_assert(FAST || !BF16, "the bf16 path exists for the FAST loaders only");
   static_assert(!TAP9 || (FAST && AOP == OP_IM2COL && BOP == OP_CONVW_P), "TAP9 is the 3x3 Cin=64 im2col specialisation");
   static_assert(!X3 || (FAST && !BF16 && BOP != OP_CONVW), "X3 exists for the FAST loaders");
-  __shared__ __attribute__((aligned(16))) float lds[X3 ? 2 * X3_BUF / 4 : 2 * (A_FLOATS + B_FLOATS)];
+  constexpr int H_NPL = X3 ? 3 : 1, H_BBUF = H_NPL * X3_B_PLANE;  // HALO: planes per operand, bytes of one weight-tile buffer
+  __shared__ __attribute__((aligned(16))) float lds[HALO ? (H_NPL * HALO_PLANE + 2 * H_BBUF) / 4 : X3 ? 2 * X3_BUF / 4 : 2 * (A_FLOATS + B_FLOATS)];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -652,7 +664,109 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
   // tile t+1 sits in register set (t+1)&1, tile t+2 in set t&1
   // tiles 0 and 1 are requested back to back (two register sets), tile 2 as soon as tile 0 has been parked in LDS: the
   // short-K launches (K = 64..192: two to six tiles) are one memory latency shorter than with "load, store, load, load"
-  if constexpr (TAP9) {
+  if constexpr (HALO) {
+    char* Hb = reinterpret_cast<char*>(lds);
+    char* Bb0 = Hb + H_NPL * HALO_PLANE;
+    const int hw = a.g.H * a.g.W;
+    const int bimg = m0 / hw, y0 = (m0 - bimg * hw) >> 6;           // W == 64: the tile is rows y0, y0 + 1 of image bimg
+    const int mrow = wm * 32 + li;
+    const int hq_base = (mrow >> 6) * 66 + (mrow & 63);             // halo pixel of this lane's A row for tap (0, 0)
+    const int rowb = wn * 32 + li;
+    float4 hreg[5];
+    auto halo_load = [&](int half) {
+#pragma unroll
+      for (int it = 0; it < 5; ++it) {
+        const int q = r0 + 64 * it, hy = q / 66, hx = q - hy * 66;
+        const int y = y0 - 1 + hy, x = hx - 1;
+        const bool ok = q < HALO_Q && (unsigned)y < (unsigned)a.g.H && (unsigned)x < (unsigned)a.g.W;
+        hreg[it] = bload4(rsrcA, (((bimg * a.g.H + y) * a.g.W + x) * a.g.ldx + half * 32 + kq * 4) * 4, ok);
+      }
+    };
+    auto halo_store = [&]() {
+#pragma unroll
+      for (int it = 0; it < 5; ++it) {
+        const int q = r0 + 64 * it;
+        if (q < HALO_Q) {
+          char* d = Hb + q * 64 + ((((kq >> 1) ^ ((q >> 1) & 3)) << 4) + ((kq & 1) << 3));
+          if constexpr (X3) {
+            uint2 p0, p1, p2;
+            split3(hreg[it], p0, p1, p2);
+            *reinterpret_cast<uint2*>(d) = p0;
+            *reinterpret_cast<uint2*>(d + HALO_PLANE) = p1;
+            *reinterpret_cast<uint2*>(d + 2 * HALO_PLANE) = p2;
+          } else {
+            *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16(hreg[it].x, hreg[it].y), pack_bf16(hreg[it].z, hreg[it].w));
+          }
+        }
+      }
+    };
+    auto load_b = [&](int tt, float4& rb) {  // tile tt: channel half tt / 9, tap tt % 9 (constants after unrolling)
+      if (tt >= 18) return;
+      rb = bload4s(rsrcB, fb_vo, ((tt % 9) * 64 + (tt / 9) * BK) * 4);
+    };
+    auto store_b = [&](int buf, const float4& rb) {
+      char* d = Bb0 + buf * H_BBUF + r0 * 64 + st_swz16;
+      if (tid < 512) {
+        if constexpr (X3) {
+          uint2 p0, p1, p2;
+          split3(rb, p0, p1, p2);
+          *reinterpret_cast<uint2*>(d) = p0;
+          *reinterpret_cast<uint2*>(d + X3_B_PLANE) = p1;
+          *reinterpret_cast<uint2*>(d + 2 * X3_B_PLANE) = p2;
+        } else {
+          *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16(rb.x, rb.y), pack_bf16(rb.z, rb.w));
+        }
+      }
+    };
+    auto compute_h = [&](int buf, int tap) {
+      const int hq = hq_base + (tap / 3) * 66 + (tap % 3);
+      const char* Bb = Bb0 + buf * H_BBUF;
+#pragma unroll
+      for (int g = 0; g < BK / 16; ++g) {
+        const char* pa = Hb + hq * 64 + (((2 * g + lh) ^ ((hq >> 1) & 3)) << 4);
+        const char* pb = Bb + rowb * 64 + (((2 * g + lh) ^ ((rowb >> 1) & 3)) << 4);
+        if constexpr (X3) {
+          uint4 av[3], bv[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            av[p] = *reinterpret_cast<const uint4*>(pa + p * HALO_PLANE);
+            bv[p] = *reinterpret_cast<const uint4*>(pb + p * X3_B_PLANE);
+          }
+#define X3_MFMA(i, j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc, 0, 0, 0)
+          X3_MFMA(2, 0); X3_MFMA(1, 1); X3_MFMA(0, 2);
+          X3_MFMA(1, 0); X3_MFMA(0, 1);
+          X3_MFMA(0, 0);
+#undef X3_MFMA
+        } else {
+          uint4 au = *reinterpret_cast<const uint4*>(pa), bu = *reinterpret_cast<const uint4*>(pb);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&au), *reinterpret_cast<bf16x8*>(&bu), acc, 0, 0, 0);
+        }
+      }
+    };
+    halo_load(0);
+    load_b(0, rb0);
+    load_b(1, rb1);
+    halo_store();
+    store_b(0, rb0);
+    load_b(2, rb0);
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 18; tt += 2) {
+      store_b(1, rb1);
+      load_b(tt + 3, rb1);
+      if (tt == 4) halo_load(1);                 // the other 32 channels: requested five tiles before they are needed
+      compute_h(0, tt % 9);
+      __syncthreads();
+      if (tt == 8) {                             // tile 8 was the last one of the first channel half: swap the halo
+        halo_store();
+      }
+      if (tt + 2 < 18) store_b(0, rb0);
+      load_b(tt + 4, rb0);
+      if (tt == 8) __syncthreads();
+      compute_h(1, (tt + 1) % 9);
+      if (tt + 2 < 18) __syncthreads();
+    }
+  } else if constexpr (TAP9) {
     int va[9][2];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -849,6 +963,16 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
 template <int AOP, int BOP, bool TAP9 = false, int EPI = 0>
 __global__ __launch_bounds__(NTHR, 2) void gemm_x3_kernel(GemmArgs a) {
   gemm_body<AOP, BOP, true, false, TAP9, EPI, true>(a);
+}
+// TAP9 launches on 64-wide maps in bf16 (X3 = false) or split-product (X3 = true) precision with the input halo resident in LDS
+template <int AOP, int BOP, int EPI, bool X3>
+__global__ __launch_bounds__(NTHR, 2) void gemm_halo_kernel(GemmArgs a) {
+  gemm_body<AOP, BOP, true, !X3, true, EPI, X3, true>(a);
+}
+const int g_halo = [] { const char* e = getenv("TATT_CONV_HALO"); return (e && e[0] == '0') ? 0 : 1; }();  // =0: per-tap loads (A/B runs)
+inline bool halo_ok(const GemmArgs& a) {
+  return g_halo && a.bf16 != 0 && a.g.W == 64 && a.g.H % 2 == 0 && a.M % BM == 0 && a.M == (a.M / (a.g.H * a.g.W)) * a.g.H * a.g.W &&
+         (long)a.M * a.g.ldx * 4 < (1L << 31);
 }
 template <int AOP, int BOP>
 constexpr bool x3_ok = BOP != OP_CONVW;
@@ -1151,7 +1275,10 @@ int launch(const GemmArgs& a, int batch, hipStream_t st) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch * a.splitk);
   if constexpr (AOP == OP_IM2COL && BOP == OP_CONVW_P) {  // 3x3, Cin = 64, packed weights, whole K in one pass: tap-unrolled loop
     if (g_tap9 && fast_ok<AOP, BOP>(a) && a.g.Cin == 64 && a.g.KH == 3 && a.g.KW == 3 && a.splitk == 1 && a.K == 576 && a.w_stap == 64) {
-      if (a.bf16 == 1) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, true>), grid, dim3(NTHR), 0, st, a);
+      if (halo_ok(a)) {
+        if (a.bf16 == 1) hipLaunchKernelGGL((gemm_halo_kernel<AOP, BOP, 0, false>), grid, dim3(NTHR), 0, st, a);
+        else hipLaunchKernelGGL((gemm_halo_kernel<AOP, BOP, 0, true>), grid, dim3(NTHR), 0, st, a);
+      } else if (a.bf16 == 1) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, true>), grid, dim3(NTHR), 0, st, a);
       else if (a.bf16 == 2) hipLaunchKernelGGL((gemm_x3_kernel<AOP, BOP, true>), grid, dim3(NTHR), 0, st, a);
       else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, false, true>), grid, dim3(NTHR), 0, st, a);
       TATT_LAUNCH_CHECK("gemm_kernel<tap9>");
@@ -1184,7 +1311,10 @@ int launch_epi(const GemmArgs& a, hipStream_t st) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), 1);
   if constexpr (AOP == OP_IM2COL && BOP == OP_CONVW_P) {
     if (g_tap9 && a.g.Cin == 64 && a.g.KH == 3 && a.g.KW == 3 && a.K == 576 && a.w_stap == 64) {
-      if (a.bf16 == 1) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, true, EPI>), grid, dim3(NTHR), 0, st, a);
+      if (halo_ok(a)) {
+        if (a.bf16 == 1) hipLaunchKernelGGL((gemm_halo_kernel<AOP, BOP, EPI, false>), grid, dim3(NTHR), 0, st, a);
+        else hipLaunchKernelGGL((gemm_halo_kernel<AOP, BOP, EPI, true>), grid, dim3(NTHR), 0, st, a);
+      } else if (a.bf16 == 1) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, true, EPI>), grid, dim3(NTHR), 0, st, a);
       else if (a.bf16 == 2) hipLaunchKernelGGL((gemm_x3_kernel<AOP, BOP, true, EPI>), grid, dim3(NTHR), 0, st, a);
       else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, false, true, EPI>), grid, dim3(NTHR), 0, st, a);
       TATT_LAUNCH_CHECK("gemm_kernel<tap9, bn epilogue>");

@@ -57,7 +57,8 @@ def test_gemm_all_layouts(M, N, K):
     close(out, r16(A) @ r16(B_).t(), 5e-6, "tt")
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(2, 16, 64, 64, 64, 3), (2, 16, 64, 64, 256, 3), (3, 8, 32, 32, 64, 3), (1, 32, 128, 64, 4, 9)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(2, 16, 64, 64, 64, 3), (2, 16, 64, 64, 256, 3), (3, 8, 32, 32, 64, 3), (1, 32, 128, 64, 4, 9),
+                                              (2, 3, 64, 64, 64, 3), (3, 4, 64, 64, 64, 3)])   # odd H: per-tap loader; even H, W = 64: LDS halo
 def test_conv_fwd_dgrad_wgrad(B, H, W, Cin, Cout, k):
     x, dy = rnd(B, Cin, H, W), rnd(B, Cout, H, W, seed=3)
     w, b = rnd(Cout, Cin, k, k, seed=1) / math.sqrt(Cin * k * k), rnd(Cout, seed=2)

@@ -81,7 +81,10 @@ def test_gemm_nt(M, N, K):
     both(run2, ref2, "gemm nt, wide dynamic range")
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 64, 64, 64), (2, 16, 64, 64, 256), (3, 8, 32, 32, 64), (5, 4, 8, 128, 256), (64, 16, 64, 64, 64)])
+# (2,16,64,..) / (64,16,64,..): 64-wide maps with an even number of rows take the LDS-halo kernel; (2,3,64,..) (odd H) and (1,2,64,..)
+# take the tap-unrolled per-tap loader; the others the generic loop
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 64, 64, 64), (2, 16, 64, 64, 256), (3, 8, 32, 32, 64), (5, 4, 8, 128, 256), (64, 16, 64, 64, 64),
+                                            (2, 3, 64, 64, 64), (1, 2, 64, 64, 64), (3, 4, 64, 64, 64)])
 def test_conv3x3_fwd_dgrad(B, H, W, Cin, Cout):
     x, dy = rnd(B, Cin, H, W), rnd(B, Cout, H, W, seed=3)
     w, b = rnd(Cout, Cin, 3, 3, seed=1) / math.sqrt(Cin * 9), rnd(Cout, seed=2)
