@@ -292,12 +292,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
         if (m < a.M) fa_vo[j] = (int)(((long)m * a.sam + kq * 4) * 4);
       } else if constexpr (AOP == OP_ROWCONTIG) {
         const int m = m0 + (tid & 31) * 4;
-        fa_k[j] = (tid >> 5) + 16 * j;
+        fa_k[j] = X3 ? 2 * (tid >> 5) + j : (tid >> 5) + 16 * j;  // X3: a thread holds (k, k + 1) of its four rows -- the bf16 pairs
         if (m < a.M) fa_vo[j] = (int)(((long)fa_k[j] * a.sak + m) * 4);
       } else if constexpr (AOP == OP_IM2COL) {
         fa_vo[j] = a_off[j] + kq * 16;
       } else {  // OP_IM2COL_M
-        fa_k[j] = (tid >> 5) + 16 * j;
+        fa_k[j] = X3 ? 2 * (tid >> 5) + j : (tid >> 5) + 16 * j;
         fa_x[j] = fa_k[j] + am_tap_dx;
         fa_vo[j] = am_off + fa_k[j] * a.g.ldx * 4;
       }
@@ -500,22 +500,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
       char* Bb = Ab + 3 * X3_A_PLANE;
       uint2 p0, p1, p2;
       if constexpr (AOP == OP_ROWCONTIG || AOP == OP_IM2COL_M) {
-        // row-contiguous source: a thread holds 4 rows at ONE k, the bf16 dwords need (k, k+1) of one row.  Lanes l and l ^ 32 hold
-        // k even / odd of the same rows: they swap half of their rows, then each splits (k, k+1) pairs of two rows.  Plane layout
-        // [k pair 16][row] dwords: conflict-free 8-byte stores here, four ds_read_b32 per fragment in compute().
-        const int h = lane >> 5;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float4 my = ra[j];
-          const float s0 = h ? my.x : my.z, s1 = h ? my.y : my.w;
-          const float q0 = __shfl_xor(s0, 32, 64), q1 = __shfl_xor(s1, 32, 64);
-          const float4 v = h ? make_float4(q0, my.z, q1, my.w) : make_float4(my.x, q0, my.y, q1);
-          split3(v, p0, p1, p2);
-          char* d = Ab + (((wave + 8 * j) * BM + (tid & 31) * 4 + 2 * h) << 2);
-          *reinterpret_cast<uint2*>(d) = p0;
-          *reinterpret_cast<uint2*>(d + X3_A_PLANE) = p1;
-          *reinterpret_cast<uint2*>(d + 2 * X3_A_PLANE) = p2;
-        }
+        // row-contiguous source: the bf16 dwords need (k, k+1) of one row, so under X3 the loader gives a thread k = 2 (tid >> 5)
+        // and k + 1 of its four rows (fa_k above).  Plane layout [k pair 16][row] dwords: one 16-byte store per plane here, four
+        // ds_read_b32 per fragment in compute().
+        // (the thread's two loads are k = 2 (tid >> 5) and k + 1 of the same four rows: no lane exchange)
+        uint2 u0, u1, u2;
+        split3(make_float4(ra[0].x, ra[1].x, ra[0].y, ra[1].y), p0, p1, p2);
+        split3(make_float4(ra[0].z, ra[1].z, ra[0].w, ra[1].w), u0, u1, u2);
+        char* d = Ab + (((tid >> 5) * BM + (tid & 31) * 4) << 2);
+        *reinterpret_cast<uint4*>(d) = make_uint4(p0.x, p0.y, u0.x, u0.y);
+        *reinterpret_cast<uint4*>(d + X3_A_PLANE) = make_uint4(p1.x, p1.y, u1.x, u1.y);
+        *reinterpret_cast<uint4*>(d + 2 * X3_A_PLANE) = make_uint4(p2.x, p2.y, u2.x, u2.y);
       } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
