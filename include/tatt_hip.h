@@ -149,8 +149,8 @@ int tatt_rpe_step_fwd(const float* gi, const float* whh_f, const float* whh_b, c
  * per XCD (chain = XCC id + n_xcd * group; n_xcd from hipDeviceAttributeNumberOfXccs), 32 workgroups per chain keep their W_hh slice in
  * registers and hand h_s over through flag lines in that XCD's L2; every wait is bounded.  No counterpart call in the reference (it is
  * nn.GRU's time loop, model/transformer_v2.py:177,:215-221).  hstep [2][B+1][64][512] (h_0 set by the caller), gh_all [2][B][64][1536];
- * sync: device buffer of tatt_rpe_chain_sync_words(B) uint32, zeroed by the call on `stream`; sync[1] != 0 afterwards = a wait gave
- * up (results invalid).  Needs the GPU's CUs free enough to hold 32 workgroups of 512 threads per XCD at once; two calls that
+ * sync: device buffer of tatt_rpe_chain_sync_words(B) uint32 that the caller zeroes ONCE; every call clears its working part on `stream`
+ * but not the first 8 words: sync[1] collects error flags across calls (sticky) -- != 0 = some call's wait gave up (its results are invalid).  Needs the GPU's CUs free enough to hold 32 workgroups of 512 threads per XCD at once; two calls that
  * share a sync buffer must not overlap.  Returns TATT_ERR_ARG when tatt_rpe_chain_supported() is 0. */
 size_t tatt_rpe_chain_supported(void);   /* 1: the current device can hold the chains (8 XCDs x >= 32 CUs, or fewer XCDs with room for their share); 0: use the step kernels */
 size_t tatt_rpe_chain_sync_words(int B);

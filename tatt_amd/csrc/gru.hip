@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64 * NWV) void rpe_step_fwd(const float* __restrict
 //     with what is there (wrong numbers and an error flag, never a hang) -- e.g. if an XCD ever received fewer than 32 workgroups.
 //   * gh and query_pos are only read by later kernels (ordinary stores; visible at the end of the kernel like any output).
 constexpr unsigned RPE_SPIN_LIMIT = 1u << 18;  // polls of ~1-2 us each before a reader gives up
-constexpr int RPE_SYNC_WORDS = 32 * 9 + 8 * 1024;          // sync[1] error flags; sync[32 * (1 + x)] XCD x's ticket counter (a line of its own); then per chain [reader 32][writer 32] flag words
+constexpr int RPE_SYNC_WORDS = 32 * 9 + 8 * 1024;          // sync[0..7]: header the calls do NOT clear -- sync[1] sticky error flags (caller zeroes the buffer once); sync[32 * (1 + x)] XCD x's ticket counter (a line of its own); then per chain [reader 32][writer 32] flag words
 // read a word AT the L2 of this XCD (returning atomic OR of 0: a plain load could be served from the CU's cache for ever)
 __device__ __forceinline__ unsigned l2_read(unsigned* p) {
   unsigned v;
@@ -773,7 +773,7 @@ int tatt_rpe_chain_fwd(const float* gi, const float* whh_f, const float* whh_b, 
   TATT_CHECK_ARG(2L * (B + 1) * RW * RH * 4 < (1L << 31) && dir_stride_h >= (long)(B + 1) * RW * RH, "tatt_rpe_chain_fwd: hstep too large / bad stride");
   TATT_CHECK_ARG(tatt_rpe_chain_supported(), "tatt_rpe_chain_fwd: this device cannot hold the chains (tatt_rpe_chain_supported() == 0): use the per-step kernels");
   const int nxcd = rpe_num_xcd();
-  if (hipMemsetAsync(sync, 0, tatt_rpe_chain_sync_words(B) * 4, st) != hipSuccess) {
+  if (hipMemsetAsync(sync + 8, 0, (tatt_rpe_chain_sync_words(B) - 8) * 4, st) != hipSuccess) {
     tatt_set_error("tatt_rpe_chain_fwd: hipMemsetAsync failed");
     return TATT_ERR_LAUNCH;
   }
@@ -792,7 +792,7 @@ int tatt_rpe_chain_bwd(const float* gi, const float* gh_all, const float* bhh_f,
                  "tatt_rpe_chain_bwd: bad arguments");
   TATT_CHECK_ARG(tatt_rpe_chain_supported(), "tatt_rpe_chain_bwd: this device cannot hold the chains (tatt_rpe_chain_supported() == 0): use the per-step kernels");
   const int nxcd = rpe_num_xcd();
-  if (hipMemsetAsync(sync, 0, tatt_rpe_chain_sync_words(B) * 4, st) != hipSuccess) {
+  if (hipMemsetAsync(sync + 8, 0, (tatt_rpe_chain_sync_words(B) - 8) * 4, st) != hipSuccess) {
     tatt_set_error("tatt_rpe_chain_bwd: hipMemsetAsync failed");
     return TATT_ERR_LAUNCH;
   }

@@ -77,6 +77,7 @@ class Engine:
         # self.px: what a call site pinned with fp32=True gets -- 0 (fp32 MFMA) unless the mode itself has fp32 accuracy (f32x3).
         self.pf, self.pl, self.px = 0, 0, 0
         self._rpe_chain_ok = None
+        self._rpe_sync = self._rpe_sync_b = None
         self.ws_side = None
         self.wgrad_mode = os.environ.get("TATT_WGRAD_STREAM", "batch")
         if self.wgrad_mode not in ("batch", "off"):
@@ -178,8 +179,9 @@ class Engine:
         return self._rpe_chain_ok
 
     def check_rpe_chain(self):
-        """Raise if a single-launch RPE chain (tatt_rpe_chain_fwd / _bwd) of the last pass reported a reader that gave up waiting
-        (sync word 1 != 0: the pass's numbers are then invalid).  Synchronises; call it at check points, not per step."""
+        """Raise if a single-launch RPE chain (tatt_rpe_chain_fwd / _bwd) of ANY pass since the engine was built reported a reader
+        that gave up waiting (sync word 1 is sticky: the calls never clear it; that pass's numbers were invalid).  Synchronises;
+        call it at check points, not per step."""
         for name in ("_rpe_sync", "_rpe_sync_b"):
             t = getattr(self, name, None)
             if t is not None and int(t[1].item()) != 0:
@@ -709,7 +711,8 @@ class Engine:
                             ws=self.ws_side)
                 hstep = self.zeros(2, B + 1, 64, 512)
                 if self.rpe_chain():   # the whole chain as one launch of persistent workgroups (tatt_rpe_chain_fwd)
-                    self._rpe_sync = torch.empty(L.rpe_chain_sync_words(B), device=self.dev, dtype=torch.int32)
+                    if self._rpe_sync is None or self._rpe_sync.device != self.dev:   # once per engine: word 1 is a sticky error flag
+                        self._rpe_sync = torch.zeros(L.rpe_chain_sync_words(B), device=self.dev, dtype=torch.int32)
                     L.rpe_chain_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep, gh_all, qp, B, dsg, dsh,
                                     self._rpe_sync)
                 else:
@@ -984,7 +987,8 @@ class Engine:
             with torch.cuda.stream(side):
                 L.rpe_whh_transpose(whh_f, whh_b, whhT)
                 if self.rpe_chain():   # the whole BPTT chain as one launch of persistent workgroups (tatt_rpe_chain_bwd)
-                    self._rpe_sync_b = torch.empty(L.rpe_chain_sync_words(B), device=self.dev, dtype=torch.int32)
+                    if self._rpe_sync_b is None or self._rpe_sync_b.device != self.dev:
+                        self._rpe_sync_b = torch.zeros(L.rpe_chain_sync_words(B), device=self.dev, dtype=torch.int32)
                     L.rpe_chain_bwd(gi, gh_all, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep, dqp, carry, dgh_all, dgi_sum, whhT,
                                     B, dsg, dsh, self._rpe_sync_b)
                 else:

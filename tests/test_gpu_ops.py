@@ -332,7 +332,8 @@ def test_rpe_fused_steps_vs_torch_gru(B, chain):
     qp = torch.empty(B, 16, 64, 64, device="cuda")
     dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
     bf, bb = W["bias_hh_l0"], W["bias_hh_l0_reverse"]
-    sync = torch.full((L().rpe_chain_sync_words(B),), 7, device="cuda", dtype=torch.int32)      # the call zeroes it itself
+    sync = torch.full((L().rpe_chain_sync_words(B),), 7, device="cuda", dtype=torch.int32)      # the call clears its working part itself,
+    sync[:8] = 0                                                                                 # the 8-word header (sticky error flags) is the caller's
     if chain:
         assert L().rpe_chain_supported() == 1, "an MI355X in its default partition mode holds the chains (8 XCDs x 32 CUs)"
     if chain:
