@@ -955,8 +955,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
   gemm_body<AOP, BOP, FAST, BF16, TAP9, EPI, false>(a);
 }
 // the same launches with fp32 products made of three bf16 pieces per operand (flag TATT_F32X3, see gemm_body)
+// (second launch-bound argument = waves per SIMD in HIP: four, i.e. two workgroups per CU and at most 128 registers -- with "2" one
+//  rarely used instantiation took 133 and would have run one workgroup per CU)
 template <int AOP, int BOP, bool TAP9 = false, int EPI = 0>
-__global__ __launch_bounds__(NTHR, 2) void gemm_x3_kernel(GemmArgs a) {
+__global__ __launch_bounds__(NTHR, 4) void gemm_x3_kernel(GemmArgs a) {
   gemm_body<AOP, BOP, true, false, TAP9, EPI, true>(a);
 }
 // TAP9 launches on 64-wide maps in bf16 (X3 = false) or split-product (X3 = true) precision with the input halo resident in LDS
