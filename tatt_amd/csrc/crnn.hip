@@ -5,6 +5,7 @@
 //   * linear_f64     : the `embedding` Linear that the reference evaluates in float64 (crnn.py:31-33)
 // The 3x3 convolutions, BatchNorm and the input projections run on the GEMM/conv/norm kernels of the SR path.
 #include "common.h"
+#include <cstdint>
 
 namespace {
 
@@ -96,25 +97,49 @@ __global__ void maxpool_gen_k(const float* __restrict__ x, float* __restrict__ y
 }
 
 // ---- out[r][n] = float( b[n] + sum_k double(x[r][k]) * double(W[n][k]) ) ----------------------------------------------------
+// v_mfma_f64_16x16x4_f64: a wave owns a 16 x 16 output tile (four waves = 64 rows x 16 columns per workgroup); lane (i = lane & 15,
+// q = lane >> 4) loads four consecutive k (k0 + 4 q ..) of row / column i as one float4 and feeds element e to the e-th of four
+// MFMAs -- A and B use the same (q, e) -> k map, so 16 k are consumed per trip with one load per operand.  (The first version was
+// one thread per output with two LDS reads and two conversions per fp64 FMA: VALU-issue bound, 47 us for the 1664 x 256 x 512 call.)
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4k(const float* __restrict__ p, long row_off, int k, int K, bool row_ok, bool vec) {
+  if (!row_ok) return make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec && k + 3 < K) return *reinterpret_cast<const float4*>(p + row_off + k);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < K) v.x = p[row_off + k];
+  if (k + 1 < K) v.y = p[row_off + k + 1];
+  if (k + 2 < K) v.z = p[row_off + k + 2];
+  if (k + 3 < K) v.w = p[row_off + k + 3];
+  return v;
+}
 __global__ __launch_bounds__(256) void linear_f64_k(const float* __restrict__ x, long ldx, const float* __restrict__ Wt,
                                                     const float* __restrict__ bias, float* __restrict__ out, long ldo, int R, int N,
                                                     int K) {
-  __shared__ float xs[16][65], ws[16][65];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int r0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
-  double acc = 0.0;
-  for (int k0 = 0; k0 < K; k0 += 64) {
-    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-      const int rr = e >> 6, kk = e & 63;
-      xs[rr][kk] = (r0 + rr < R && k0 + kk < K) ? x[(long)(r0 + rr) * ldx + k0 + kk] : 0.f;
-      ws[rr][kk] = (n0 + rr < N && k0 + kk < K) ? Wt[(long)(n0 + rr) * K + k0 + kk] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int kk = 0; kk < 64; ++kk) acc += (double)xs[ty][kk] * (double)ws[tx][kk];
-    __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int r0 = blockIdx.x * 64 + wv * 16, n0 = blockIdx.y * 16;
+  const bool xv = (ldx % 4 == 0) && ((((uintptr_t)x) & 15) == 0), wvec = (K % 4 == 0) && ((((uintptr_t)Wt) & 15) == 0);
+  const bool rok = r0 + i < R, nok = n0 + i < N;
+  const long xo = (long)(r0 + i) * ldx, wo = (long)(n0 + i) * K;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  float4 a = ld4k(x, xo, 4 * q, K, rok, xv), b = ld4k(Wt, wo, 4 * q, K, nok, wvec);
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const float4 an = ld4k(x, xo, k0 + 16 + 4 * q, K, rok, xv), bn = ld4k(Wt, wo, k0 + 16 + 4 * q, K, nok, wvec);  // next trip's operands
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a.x, (double)b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a.y, (double)b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a.z, (double)b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a.w, (double)b.w, acc, 0, 0, 0);
+    a = an;
+    b = bn;
   }
-  if (r0 + ty < R && n0 + tx < N) out[(long)(r0 + ty) * ldo + n0 + tx] = (float)(acc + (bias ? (double)bias[n0 + tx] : 0.0));
+  // D layout of the f64 instruction: lane (i, q), register r holds row 4 r + q of column i (unlike f32 16x16x4: row 4 q + r)
+  const int n = n0 + i;
+  if (n >= N) return;
+  const double bv = bias ? (double)bias[n] : 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = r0 + 4 * r + q;
+    if (row < R) out[(long)row * ldo + n] = (float)(acc[r] + bv);
+  }
 }
 
 // ---- LSTM step (hidden 256, gate order i, f, g, o; torch nn.LSTM) ---------------------------------------------------------
@@ -457,7 +482,7 @@ int tatt_maxpool_gen_fwd(const float* x, float* y, int B, int H, int W, int C, i
 int tatt_linear_f64(const float* x, long ldx, const float* Wt, const float* bias, float* out, long ldo, int R, int N, int K,
                     hipStream_t st) {
   TATT_CHECK_ARG(x && Wt && out && R > 0 && N > 0 && K > 0, "tatt_linear_f64: bad arguments");
-  hipLaunchKernelGGL(linear_f64_k, dim3(cdiv(R, 16), cdiv(N, 16)), dim3(256), 0, st, x, ldx, Wt, bias, out, ldo, R, N, K);
+  hipLaunchKernelGGL(linear_f64_k, dim3(cdiv(R, 64), cdiv(N, 16)), dim3(256), 0, st, x, ldx, Wt, bias, out, ldo, R, N, K);
   TATT_LAUNCH_CHECK("linear_f64");
   return TATT_OK;
 }
