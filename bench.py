@@ -3,6 +3,8 @@
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py --gpus N ...        (no WORLD_SIZE in the environment: starts the line above itself as a child process, before
+                                       this process has touched a GPU, relays rank 0's JSON line and exits with the child's code)
 
 Workload = BASELINE config 2 per GPU: TSRN_TL_TRANS(STN=True, K=37) random init, train mode (dropout 0.1, BN batch
 stats), fp32, batch 64 synthetic TextZoom-shaped images, frozen (precomputed) CRNN-shaped text prior,
@@ -117,6 +119,40 @@ def cpu_baseline(state, B, K, steps=5):
             "sample": f"median of {steps} training steps of the same config-2 workload (B={B}) after 1 warm-up, torch {torch.__version__} CPU"}
 
 
+def launch_command(n, argv, port):
+    """The torch.distributed.run command line of an N-rank run of this script (one process per GPU, one node, rendezvous on
+    127.0.0.1): what `python bench.py --gpus N` starts when it was not itself started by a launcher."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """Run the N-rank job as a child process and relay it: stdout lines are passed through as they come (rank 0 prints the one
+    JSON line), the exit code is the child's.  Nothing in this process has initialised a GPU (no HIP call, no
+    torch.cuda.is_available()), and the child is started, not exec'd."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launch_command(n, argv, int(os.environ.get("MASTER_PORT", 0)) or free_port())
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if rc != 0:
+        print(f"bench.py: the {n}-rank child run failed with exit code {rc}", file=sys.stderr, flush=True)
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,12 +174,17 @@ def main():
     ap.add_argument("--no-stn", action="store_true", help="experiment: the network without its STN head / TPS rectification (not a BASELINE config)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    ndev = torch.cuda.device_count()
+    if local >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} (local rank {local}) has no GPU: this node shows {ndev} device(s), the run needs {world} "
+                         "(one process per GPU)")
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -159,7 +200,8 @@ def main():
     state_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.cuda().train()
     model.matmul_precision = "bf16" if a.bf16 else "f32x3" if a.f32x3 else "fp32"
-    kw = dict(lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, loss_weight=(1.0, 1e-4), use_graph=not a.no_graph, tsc=a.tsc)
+    kw = dict(lr=1e-3, betas=(0.5, 0.999), max_norm=0.25, loss_weight=(1.0, 1e-4), use_graph=not a.no_graph, tsc=a.tsc,
+              strict_graph=True)            # a failed capture raises: no eager number under a hipGraph headline
     if a.full:
         from tatt_amd.model.crnn import CRNN
         from tatt_amd.trainer import TATTTrainer

@@ -99,8 +99,11 @@ int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, flo
 int tatt_conv_pack_w(const float* Wt, float* Wf, float* Wd, int Cout, int Cin, int KH, int KW, hipStream_t stream);
 /* The same for n <= 32 layers in one launch (host arrays of length n; KHW[i] = KH*KW of layer i). */
 int tatt_conv_pack_w_group(int n, const float* const* Wt, float* const* Wf, float* const* Wd, const int* Cout, const int* Cin, const int* KHW, hipStream_t stream);
-/* Cout in {4,8,16} (9x9 64->4 output conv model/tsrn.py:625 and the dgrad of the 9x9 4->64 conv :598): dense planar GEMM
- * Z[(tap,co)][pixel] followed by a shifted gather-sum, instead of padding Cout to the 64-wide MFMA tile. */
+/* Cout in {4,8,16}, instead of padding Cout to the 64-wide MFMA tile.  The 9x9 convolutions with FOUR output channels (the 64->4
+ * output conv model/tsrn.py:625 and the dgrad of the 9x9 4->64 conv :598; Cin a multiple of 8) run as a direct VALU convolution: an
+ * 8x64-pixel tile + halo of eight input channels at a time in LDS, no intermediate; workspace = the packed weights only, and the call
+ * needs ldx % 4 == 0 and a 16-byte aligned X (refused with TATT_ERR_ARG otherwise).  Every other shape: dense planar GEMM
+ * Z[(tap,co)][pixel] into the workspace followed by a shifted gather-sum. */
 size_t tatt_conv_skinny_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW);
 int tatt_conv_skinny_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int flags, float* workspace, hipStream_t stream);
 size_t tatt_conv_wgrad_workspace(int Cin, int Cout, int KH, int KW, int splitk);

@@ -66,6 +66,9 @@ def save_checkpoint(netG_list, epoch, iters, best_acc_dict, best_model_info, is_
     os.makedirs(ckpt_path, exist_ok=True)
     netG = netG_list[0]
     netG = getattr(netG, "module", netG)
+    eng = getattr(netG, "_engine", None)
+    if eng is not None:
+        eng.check_rpe_chain()          # a checkpoint must not hold weights trained through an RPE chain that reported a timed-out wait
     cpu = lambda sd: OrderedDict((k, v.detach().cpu().clone()) for k, v in sd.items())
     save_dict = {
         "state_dict_G": cpu(netG.state_dict()),

@@ -1551,6 +1551,12 @@ int tatt_conv_skinny_fwd(const float* X, const float* Wt, const float* bias, flo
   const int T = KH * KW;
   const long P = (long)B * H * W;
   TATT_CHECK_ARG(P < (1L << 31), "tatt_conv_skinny_fwd: too many pixels");
+  // tatt_conv_skinny_workspace() sizes the workspace for the direct kernel whenever the SHAPE is eligible (it cannot see ldx or X): a
+  // call of that shape whose operand layout rules the direct kernel out must not fall through to the planar path, which would write
+  // T*Cout*P floats into a workspace of T*Cout*Cin
+  TATT_CHECK_ARG(!c4_direct_ok(Cin, Cout, KH, KW, 4, nullptr) || c4_direct_ok(Cin, Cout, KH, KW, ldx, X),
+                 "tatt_conv_skinny_fwd: a %dx%d convolution with %d output channels needs ldx %% 4 == 0 and a 16-byte aligned X (ldx %ld)",
+                 KH, KW, Cout, ldx);
   if (c4_direct_ok(Cin, Cout, KH, KW, ldx, X)) {  // 9x9, four output channels: direct convolution, no planar intermediate
     hipLaunchKernelGGL(conv_c4_pack_w, dim3(cdiv((long)T * Cin * 4, 256)), dim3(256), 0, st, Wt, workspace, Cin, T, w_sn, w_sci, w_base, w_stap);
     TATT_LAUNCH_CHECK("conv_c4_pack_w");

@@ -269,7 +269,7 @@ class Engine:
 
     def _skinny(self, x, W, b, out, B, H, Wd, Cin, Cout, k, wstr, acc, fp32=False):
         wsz = self.L.conv_skinny_workspace(B, H, Wd, Cin, Cout, k, k)
-        z = self.new(wsz)                                      # planar Z [(tap,co)][pixel]: 340 MB for the output conv at B=64
+        z = self.new(wsz)                                      # 9x9, Cout = 4 (direct kernel): the packed weights; else planar Z [(tap,co)][pixel]
         self.L.conv_skinny_fwd(x, W, b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout, *wstr, acc | (self.px if fp32 else self.pf), z)
 
     def _prepack(self, use_stn):

@@ -77,4 +77,7 @@ def evaluate(model, stu_model, test_rec_model, val_loader, stu_iter=1, filter_mo
     md["psnr_avg"], md["ssim_avg"] = round(psnr_avg.item(), 6), round(ssim_avg.item(), 6)
     md["psnr_lr_avg"] = round((sum(md["psnr_lr"]) / (len(md["psnr_lr"]) + 1e-10)).item(), 6)
     md["ssim_lr_avg"] = round((sum(md["ssim_lr"]) / (len(md["ssim_lr"]) + 1e-10)).item(), 6)
+    eng = getattr(model, "_engine", None)
+    if eng is not None:
+        eng.check_rpe_chain()          # the metrics above already synchronised; a timed-out RPE chain invalidates them
     return md

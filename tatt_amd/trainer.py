@@ -63,13 +63,22 @@ def allreduce_mean(t, async_op=False):
 
 
 def replica_fingerprint(t):
-    """(sum, sum of squares, bit-pattern checksum) of a flat fp32 buffer as three float64 values: equal on every rank iff the
-    replicas hold bit-identical parameters (up to a 2^-53-ish chance for the sums, none for the integer checksum below 2^53)."""
-    bits = t.detach().contiguous().view(torch.int32).to(torch.int64)
-    w = torch.arange(1, bits.numel() + 1, device=t.device, dtype=torch.int64) % 8191 + 1      # position-dependent weights
-    chk = int(((bits & 0xFFFF) * w).sum().item() % (1 << 52))
-    d = t.detach().double()
-    return torch.tensor([d.sum().item(), (d * d).sum().item(), float(chk)], dtype=torch.float64, device=t.device)
+    """(sum, sum of squares, two bit-pattern checksums) of a flat fp32 buffer as four float64 values: equal on every rank iff the
+    replicas hold bit-identical parameters (up to a 2^-53-ish chance for the sums).  The checksums are position-weighted sums of
+    the low and of the high 16 bits of every word (sign, exponent and the top mantissa bits are in the high half), computed in
+    chunks so that the int64 temporaries stay small."""
+    flat = t.detach().contiguous().view(-1)
+    bits = flat.view(torch.int32)
+    lo = hi = 0
+    step = 1 << 20
+    for a in range(0, bits.numel(), step):
+        b = bits[a:a + step].to(torch.int64)
+        w = (torch.arange(a + 1, a + 1 + b.numel(), device=t.device, dtype=torch.int64) % 8191) + 1   # position-dependent weights
+        lo += int(((b & 0xFFFF) * w).sum().item())
+        hi += int((((b >> 16) & 0xFFFF) * w).sum().item())
+    d = flat.double()
+    return torch.tensor([d.sum().item(), (d * d).sum().item(), float(lo % (1 << 52)), float(hi % (1 << 52))], dtype=torch.float64,
+                        device=t.device)
 
 
 def assert_replicas_identical(t, what="parameters"):
@@ -89,7 +98,8 @@ def assert_replicas_identical(t, what="parameters"):
 
 class SRTrainer:
     def __init__(self, model, lr=1e-3, betas=(0.5, 0.999), eps=1e-8, max_norm=0.25, loss_weight=(1.0, 1e-4),
-                 use_graph=False, distributed=None, tsc=False, tssim_rotation_degree=10.0, training_stablize=False):
+                 use_graph=False, distributed=None, tsc=False, tssim_rotation_degree=10.0, training_stablize=False,
+                 strict_graph=False):
         self.model, self.L = model, lib()
         if getattr(model, "in_planes", 4) != 4:
             raise NotImplementedError("SRTrainer: the fused training step is wired for mask=True (four channels); a mask=False model "
@@ -130,6 +140,7 @@ class SRTrainer:
         self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int32)
         self.eng.seed_dev = self.seed_dev
         self.use_graph = use_graph
+        self.strict_graph = strict_graph                      # True (bench.py): a failed hipGraph capture raises instead of going eager
         self.graph = None                                     # list of captured segments (one entry without a process group)
         self.graph_update = None                              # data parallel: clip+Adam, replayed after the all-reduces
         self.static = None
@@ -336,7 +347,7 @@ class SRTrainer:
             try:
                 self._capture(lr_img, hr_img, tp, arc)
             except Exception as e:
-                if not self._is_capture_error(e):             # a kernel fault or an argument error is not a capture problem
+                if self.strict_graph or not self._is_capture_error(e):   # a kernel fault or an argument error is not a capture problem
                     raise
                 import sys
                 print(f"tatt_amd: hipGraph capture of the training step failed ({type(e).__name__}: {e}); continuing with eager "
