@@ -171,6 +171,42 @@ size_t tatt_attn_bwd_workspace(int B, int Lq);
 int tatt_attn_bwd(const float* Q, const float* Kp, const float* Vp, const float* dctx, float* dQ, float* dK, float* dV, int B, int Lq, int nkeys, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, int accumulate_kv, float* workspace, hipStream_t stream);
 int tatt_attn_avg(const float* pw, float* out, int B, int Lq, hipStream_t stream);
 
+/* dK, dV (+)= sum over chunks of the partials [nchunk][2][B*26][64] (which 0 = dV, 1 = dK) that tatt_dec_bwd writes: the reduction
+ * over the queries of torch's MultiheadAttention backward (model/transformer_v2.py:819). */
+int tatt_attn_kv_final(const float* part, int nchunk, int B, float* dK, float* dV, int accumulate_kv, hipStream_t stream);
+
+/* ---- the TP interpreter's decoder as fused launches (model/transformer_v2.py:805-832 TransformerDecoderLayer_TP.forward_post for
+ *      both layers, :368-389 TransformerDecoder incl. `self.norm` on every intermediate, model/tsrn.py:220-224 mean over the layers) ----
+ * Row-local chain per image token: q-projection of (tgt + query_pos), 26-key attention of 4 heads (softmax and dropout in
+ * registers), out-projection, residual + dropout + LayerNorm2, Linear-ReLU-dropout-Linear, residual + dropout + LayerNorm3, the
+ * decoder's final LayerNorm, mean over the two layers -> tp_map.  Keys / values are the projected text tokens Kp, Vp [B*26][64]
+ * (tatt_gemm with multihead_attn.in_proj_weight[64:128] / [128:192]) of each layer.
+ *   tatt_dec_pack_w: W = host array of 8 device pointers (layer 0 then layer 1: multihead_attn.in_proj_weight[0:64], out_proj.weight,
+ *       linear1.weight, linear2.weight; row-major [64][64]) -> packed (tatt_dec_packed_w_floats() floats): each matrix and its
+ *       transpose in MFMA-fragment order.
+ *   tatt_dec_pack_kv: one layer's (Kp, Vp) -> table (tatt_dec_kv_table_floats(B) floats): the attention's A operands.
+ *   tatt_dec_fwd: kv = host array [2] of tables; params = host array [2][8] (in_proj_bias[0:64], out_proj.bias, linear1.bias,
+ *       linear2.bias, norm2.weight, norm2.bias, norm3.weight, norm3.bias); saved = host array [2][7] of [B*Lq][64] outputs the
+ *       backward pass reads (qin, Q, context, LayerNorm2 input, LayerNorm2 output, dropped FFN hidden, LayerNorm3 input);
+ *       seed_sites = host array [2][4] of tatt_seed_site words (attention, dropout2, FFN dropout, dropout3); thresh / scale /
+ *       seed_dev as for tatt_ln_fwd.  Lq % 128 == 0.
+ *   tatt_dec_bwd: one layer (1 first, then 0).  dt3_in: gradient wrt the layer's output from the layer above (NULL for layer 1);
+ *       dtp: gradient of tp_map; dtgt / dqp (+)= the gradients wrt the layer's input and query_pos; dY = host array [4] of [B*Lq][64]
+ *       outputs (dQ, d attn-out, d hidden, d ffn-out), the left operands of the four weight gradients dY^T X with X = saved qin,
+ *       context, LayerNorm2 output, dropped hidden (tatt_tn_small_group); kvpart (tatt_dec_bwd_kvpart_floats): per-32-token partials
+ *       of dKp / dVp for tatt_attn_kv_final(nchunk = Lq/32); lnpart (tatt_dec_bwd_lnpart_floats): per-wave partials of the
+ *       LayerNorm weight / bias gradients for tatt_dec_ln_final (grads = host array [6]: norm2.weight, norm2.bias, norm3.weight,
+ *       norm3.bias, decoder.norm.weight, decoder.norm.bias; each +=). */
+size_t tatt_dec_packed_w_floats(void);
+size_t tatt_dec_kv_table_floats(int B);
+size_t tatt_dec_bwd_kvpart_floats(int B, int Lq);
+size_t tatt_dec_bwd_lnpart_floats(int B, int Lq);
+int tatt_dec_pack_w(const float* const* W, float* packed, hipStream_t stream);
+int tatt_dec_pack_kv(const float* Kp, const float* Vp, float* table, int B, hipStream_t stream);
+int tatt_dec_fwd(const float* tgt, const float* qp, const float* packed_w, const float* const* kv, const float* const* params, const float* norm_w, const float* norm_b, float* const* saved, float* tp_map, int B, int Lq, const uint32_t* seed_sites, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t stream);
+int tatt_dec_bwd(int layer, const float* dt3_in, const float* dtp, const float* packed_w, const float* kv, const float* const* params, const float* norm_w, float* const* saved, float* dtgt, int dtgt_accumulate, float* dqp, int dqp_accumulate, float* const* dY, float* kvpart, float* lnpart, int B, int Lq, const uint32_t* seed_sites, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t stream);
+int tatt_dec_ln_final(const float* lnpart, int B, int Lq, float* const* grads, hipStream_t stream);
+
 /* ---- element-wise / layout (model/tsrn.py:599 PReLU, :1042-1043 PixelShuffle+mish, :683 sigmoid, :208, :212;
  *      model/stn_head.py:36-44 MaxPool2d; model/transformer_v2.py:39-42 PE+dropout, :480 FFN dropout) -------- */
 int tatt_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, hipStream_t stream);

@@ -225,6 +225,14 @@ int tatt_attn_bwd(const float* Q, const float* Kp, const float* Vp, const float*
   return TATT_OK;
 }
 
+int tatt_attn_kv_final(const float* part, int nchunk, int B, float* dK, float* dV, int accumulate_kv, hipStream_t st) {
+  TATT_CHECK_ARG(part && dK && dV && nchunk > 0 && B > 0, "tatt_attn_kv_final: bad arguments");
+  const long n = (long)B * S * E;
+  hipLaunchKernelGGL(attn_bwd_final, dim3(cdiv(2 * n, 256)), dim3(256), 0, st, part, nchunk, n, dK, dV, accumulate_kv);
+  TATT_LAUNCH_CHECK("attn_kv_final");
+  return TATT_OK;
+}
+
 int tatt_attn_avg(const float* pw, float* out, int B, int Lq, hipStream_t st) {
   long tot = (long)B * Lq * S;
   hipLaunchKernelGGL(attn_avg_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, pw, out, B, Lq);

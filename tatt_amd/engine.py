@@ -23,6 +23,7 @@ DROP_SITES = {
 STN_STAGES = [(0, 4, 32, (2, 2)), (2, 32, 64, (2, 2)), (4, 64, 128, (2, 2)), (6, 128, 256, (2, 2)),
               (8, 256, 256, (1, 2)), (10, 256, 256, None)]
 RPE_CHAIN = os.environ.get("TATT_RPE_CHAIN", "1") != "0"   # 0: one launch per step of the RPE recurrence (A/B runs)
+DEC_FUSED = os.environ.get("TATT_DEC_FUSED", "1") != "0"   # 0: the decoder as one launch per projection / attention / LayerNorm (A/B runs)
 WS_FLOATS = 48 * 1024 * 1024
 NODROP = (0, 0, 1.0, None)
 
@@ -77,6 +78,7 @@ class Engine:
         # self.px: what a call site pinned with fp32=True gets -- 0 (fp32 MFMA) unless the mode itself has fp32 accuracy (f32x3).
         self.pf, self.pl, self.px = 0, 0, 0
         self._rpe_chain_ok = None
+        self.dec_fused = DEC_FUSED   # the TP interpreter's decoder as tatt_dec_fwd / tatt_dec_bwd (False: one launch per op; tests compare the two)
         self._rpe_sync = self._rpe_sync_b = None
         self.ws_side = None
         self.wgrad_mode = os.environ.get("TATT_WGRAD_STREAM", "batch")
@@ -571,6 +573,67 @@ class Engine:
         self.linear_dwb(dh, x, G[pre + "linear1.weight"], G[pre + "linear1.bias"], R, 64, 64)
         self.linear_dx(dh, P[pre + "linear1.weight"], dx, R, 64, 64, acc=1)
 
+    # ---- fused decoder (tatt_dec_fwd / tatt_dec_bwd): argument marshalling shared by both passes ---------------------------------
+    def _dec_params(self, li):
+        P, d = self.P, f"infoGen.transformer.decoder.layers.{li}."
+        return [P[d + "multihead_attn.in_proj_bias"], P[d + "multihead_attn.out_proj.bias"], P[d + "linear1.bias"], P[d + "linear2.bias"],
+                P[d + "norm2.weight"], P[d + "norm2.bias"], P[d + "norm3.weight"], P[d + "norm3.bias"]]
+
+    def _dec_sites(self, li, cfg):
+        c = [cfg(f"dec{li}_{k}") for k in ("attn", "drop2", "ffn", "drop3")]
+        return [x[0] for x in c], c[0][1], c[0][2], c[0][3]
+
+    def _dec_call(self, fn, layer, tgt, qp, dec_w, dec_kv, saved, tp_map, B, Lq, cfg, extra=None):
+        VP, U32 = ctypes.c_void_p, ctypes.c_uint32
+        nw, nb = self.P["infoGen.transformer.decoder.norm.weight"], self.P["infoGen.transformer.decoder.norm.bias"]
+        ptr = lambda ts: [t.data_ptr() for t in ts]
+        if layer is None:                                                  # forward: both layers
+            s0, th, sc, sdev = self._dec_sites(0, cfg)
+            s1 = self._dec_sites(1, cfg)[0]
+            fn(tgt, qp, dec_w, (VP * 2)(*ptr([kv[2] for kv in dec_kv])), (VP * 16)(*ptr(self._dec_params(0) + self._dec_params(1))), nw, nb,
+               (VP * 14)(*ptr(saved[0] + saved[1])), tp_map, B, Lq, (U32 * 8)(*(s0 + s1)), th, sc, sdev)
+            return
+        dt3_in, dtp, dtgt, dtgt_acc, dqp, dqp_acc, dY, kvpart, lnpart = extra
+        st, th, sc, sdev = self._dec_sites(layer, cfg)
+        fn(layer, dt3_in, dtp, dec_w, dec_kv[layer][2], (VP * 8)(*ptr(self._dec_params(layer))), nw, (VP * 7)(*ptr(saved[layer])), dtgt, dtgt_acc,
+           dqp, dqp_acc, (VP * 4)(*ptr(dY)), kvpart, lnpart, B, Lq, (U32 * 4)(*st), th, sc, sdev)
+
+    def _dec_bwd_fused(self, dec, dtp, db1, dqp, dkin, dmem, kin, mem, B, Lq, cfg, G):
+        """Backward of both decoder layers: two tatt_dec_bwd launches (layer 1, then layer 0 -- which adds its input gradient onto
+        db1 and its query_pos gradient onto layer 1's), the reductions of their partials, and ONE grouped launch for the eight
+        [64,64] weight gradients."""
+        L, P, tr = self.L, self.P, "infoGen.transformer."
+        _, dec_w, dec_kv, saved = dec
+        R0, Rt = B * Lq, B * 26
+        VP = ctypes.c_void_p
+        dtgt1 = self.new(R0, 64)
+        wg = []
+        for li in (1, 0):
+            d = f"{tr}decoder.layers.{li}."
+            dY = [self.new(R0, 64) for _ in range(4)]
+            kvpart, lnpart = self.new(L.dec_bwd_kvpart_floats(B, Lq)), self.new(L.dec_bwd_lnpart_floats(B, Lq))
+            if li == 0:
+                self._guard(db1)
+            self._dec_call(L.dec_bwd, li, None, None, dec_w, dec_kv, saved, None, B, Lq, cfg,
+                           extra=(None if li == 1 else dtgt1, dtp, dtgt1 if li == 1 else db1, 0 if li == 1 else 1, dqp, 0 if li == 1 else 1,
+                                  dY, kvpart, lnpart))
+            L.dec_ln_final(lnpart, B, Lq, (VP * 6)(*[G[n].data_ptr() for n in (d + "norm2.weight", d + "norm2.bias", d + "norm3.weight", d + "norm3.bias",
+                                                                            tr + "decoder.norm.weight", tr + "decoder.norm.bias")]))
+            Kp, Vp, _ = dec_kv[li]
+            dKp, dVp = self.new(Rt, 64), self.new(Rt, 64)
+            L.attn_kv_final(kvpart, Lq // 32, B, dKp, dVp, 0)
+            W = P[d + "multihead_attn.in_proj_weight"]
+            dW, db = G[d + "multihead_attn.in_proj_weight"], G[d + "multihead_attn.in_proj_bias"]
+            qin, _, c, _, t2, hd, _ = saved[li]
+            wg += [(dY[0], qin, dW, db, R0, 64, 64, None, None, None),
+                   (dY[1], c, G[d + "multihead_attn.out_proj.weight"], G[d + "multihead_attn.out_proj.bias"], R0, 64, 64, None, None, None),
+                   (dY[2], t2, G[d + "linear1.weight"], G[d + "linear1.bias"], R0, 64, 64, None, None, None),
+                   (dY[3], hd, G[d + "linear2.weight"], G[d + "linear2.bias"], R0, 64, 64, None, None, None)]
+            self.linear_dwb_group([(dKp, kin, dW[64:], db[64:], Rt, 64, 64, None, None, None), (dVp, mem, dW[128:], db[128:], Rt, 64, 64, None, None, None)])
+            self.linear_dx(dKp, W[64:], dkin, Rt, 64, 64, acc=0 if li == 1 else 1)
+            self.linear_dx(dVp, W[128:], dmem, Rt, 64, 64, acc=0 if li == 1 else 1)
+        self.linear_dwb_group(wg)
+
     def ln_fwd(self, pre, x, res, cfg, R, save_v=True):
         v = self.new(R, 64) if (res is not None and save_v) else None
         y = self.new(R, 64)
@@ -747,6 +810,24 @@ class Engine:
             mem, v2e = self.ln_fwd(e + "norm2.", s1, f_e, cfg("enc_drop2"), Rt)
             kin = self.new(Rt, 64)
             L.axpby(mem, 1.0, pos, 1.0, kin, Rt * 64, 0)
+            fused = self.dec_fused and (H * W) % 128 == 0
+            if fused:
+                # fused decoder (tatt_dec_fwd): the projected keys / values of both layers and the MFMA-order operand packs belong to
+                # the text branch -- they need the encoder memory and weights only
+                dec_w = self.new(L.dec_packed_w_floats())
+                VP = ctypes.c_void_p
+                dl = [f"{tr}decoder.layers.{li}." for li in range(2)]
+                L.dec_pack_w((VP * 8)(*[t_.data_ptr() for d_ in dl for t_ in (P[d_ + "multihead_attn.in_proj_weight"], P[d_ + "multihead_attn.out_proj.weight"],
+                                                                             P[d_ + "linear1.weight"], P[d_ + "linear2.weight"])]), dec_w)
+                dec_kv = []
+                for d_ in dl:
+                    Wi, bi = P[d_ + "multihead_attn.in_proj_weight"], P[d_ + "multihead_attn.in_proj_bias"]
+                    Kp, Vp = self.new(Rt, 64), self.new(Rt, 64)
+                    self.linear(kin, Wi[64:], bi[64:], Kp, Rt, 64, 64)
+                    self.linear(mem, Wi[128:], bi[128:], Vp, Rt, 64, 64)
+                    tab = self.new(L.dec_kv_table_floats(B))
+                    L.dec_pack_kv(Kp, Vp, tab, B)
+                    dec_kv.append((Kp, Vp, tab))
 
         # per-step weight packs of the main strand (conv weights in MFMA order, 1x1 conv folded into the GRU projections): issued
         # after the two forks, which need neither
@@ -815,7 +896,14 @@ class Engine:
         tgt = b1
         dec = []
         tp_map = self.new(R0, 64)
-        for li in range(2):
+        if fused:
+            if want_ctx:
+                saved = [[self.new(R0, 64) for _ in range(7)] for _ in range(2)]
+            else:                                                         # nobody reads them: one scratch tensor takes all the stores
+                saved = [[self.new(R0, 64)] * 7] * 2
+            self._dec_call(L.dec_fwd, None, b1, qp, dec_w, dec_kv, saved, tp_map, B, H * W, cfg)
+            dec = ("fused", dec_w, dec_kv, saved)
+        for li in range(0 if fused else 2):
             d = f"{tr}decoder.layers.{li}."
             qin = self.new(R0, 64)
             L.axpby(tgt, 1.0, qp, 1.0, qin, R0 * 64, 0)
@@ -943,7 +1031,10 @@ class Engine:
         dqp = self.new(R0, 64)
         dmem, dkin = self.new(Rt, 64), self.new(Rt, 64)
         dnext = None                                                           # grad flowing into layer li's output from above
-        for li in (1, 0):
+        fused = len(dec) > 0 and isinstance(dec[0], str)
+        if fused:
+            self._dec_bwd_fused(dec, dtp, db1, dqp, dkin, dmem, kin, mem, B, H * W, cfg, G)
+        for li in (() if fused else (1, 0)):
             d = f"{tr}decoder.layers.{li}."
             tgt, qin, att, v2, t2, ffn, v3, t3 = dec[li]
             dt3 = self.new(R0, 64) if dnext is None else dnext
@@ -960,7 +1051,8 @@ class Engine:
             axpby(dqin, 1.0, None, 0.0, dtgt, R0 * 64, 1)
             axpby(dqin, 1.0, None, 0.0, dqp, R0 * 64, 0 if last else 1)
             dnext = dtgt
-        axpby(dnext, 1.0, None, 0.0, db1, R0 * 64, 1)
+        if not fused:
+            axpby(dnext, 1.0, None, 0.0, db1, R0 * 64, 1)
         axpby(dkin, 1.0, None, 0.0, dmem, Rt * 64, 1)                     # kin = mem + pos
         # (no flush here: the decoder's and the encoder's weight gradients stay queued until rpe_finish() -- bulk kernels beside the
         #  RPE chain slow its 64 latency-bound steps down by more than the overlap returns: 9.51 -> 9.45 ms)

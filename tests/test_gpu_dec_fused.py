@@ -1,0 +1,148 @@
+"""Fused TP-interpreter decoder (tatt_dec_pack_w / _pack_kv / _fwd / _bwd / _ln_final, tatt_attn_kv_final) through the C-ABI against an
+fp64 torch statement of the two TransformerDecoderLayer_TP layers + decoder.norm + mean (model/transformer_v2.py:805-832, :368-389,
+model/tsrn.py:220-224), and the module with the fused decoder against the same module on the per-op launches (shared dropout masks)."""
+import ctypes
+
+import pytest
+import torch
+
+from oracle import procgen
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def L():
+    from tatt_amd.lib import lib
+    return lib()
+
+
+def close(got, ref, tol, what):
+    r = rel_l2(got.detach().cpu().double().numpy(), ref.detach().cpu().double().numpy())
+    assert torch.isfinite(got).all(), what
+    assert r <= tol, f"{what}: rel-L2 {r:.3e} > {tol}"
+
+
+def ln(x, w, b):
+    return torch.nn.functional.layer_norm(x, (64,), w, b, 1e-5)
+
+
+def ref_decoder(tgt, qp, layers, nw, nb, B, Lq):
+    """fp64 reference; layers: list of dicts of leaf tensors (Kp, Vp [B*26,64]; Wq, bq, Wo, bo, W1, b1, W2, b2, g2, be2, g3, be3)."""
+    tp = 0
+    for p in layers:
+        qin = tgt + qp
+        Q = (qin @ p["Wq"].t() + p["bq"]).view(B, Lq, 4, 16)
+        K = p["Kp"].view(B, 26, 4, 16)
+        V = p["Vp"].view(B, 26, 4, 16)
+        s = torch.einsum("bqhd,bkhd->bhqk", Q, K) * 0.25
+        c = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), V).reshape(B * Lq, 64)
+        a = c @ p["Wo"].t() + p["bo"]
+        t2 = ln(tgt + a, p["g2"], p["be2"])
+        f = torch.relu(t2 @ p["W1"].t() + p["b1"]) @ p["W2"].t() + p["b2"]
+        tgt = ln(t2 + f, p["g3"], p["be3"])
+        tp = tp + 0.5 * ln(tgt, nw, nb)
+    return tp
+
+
+@pytest.mark.parametrize("B,Lq", [(2, 1024), (3, 128)])
+def test_dec_fused_fwd_bwd_vs_fp64(B, Lq):
+    g = torch.Generator().manual_seed(7 + B)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).double()
+    R0, Rt = B * Lq, B * 26
+    tgt, qp = rn(R0, 64), rn(R0, 64, sc=0.5)
+    nw, nb = 1 + rn(64, sc=0.1), rn(64, sc=0.1)
+    layers = []
+    for _ in range(2):
+        p = {"Kp": rn(Rt, 64), "Vp": rn(Rt, 64)}
+        for w, b_ in (("Wq", "bq"), ("Wo", "bo"), ("W1", "b1"), ("W2", "b2")):
+            p[w], p[b_] = rn(64, 64, sc=0.15), rn(64, sc=0.1)
+        for w, b_ in (("g2", "be2"), ("g3", "be3")):
+            p[w], p[b_] = 1 + rn(64, sc=0.1), rn(64, sc=0.1)
+        layers.append(p)
+    leaves = [tgt, qp, nw, nb] + [t for p in layers for t in p.values()]
+    for t in leaves:
+        t.requires_grad_(True)
+    wout = rn(R0, 64)
+    tp_ref = ref_decoder(tgt, qp, layers, nw, nb, B, Lq)
+    (tp_ref * wout).sum().backward()
+
+    lib = L()
+    cu = lambda t: t.detach().float().contiguous().cuda()
+    VP, U32 = ctypes.c_void_p, ctypes.c_uint32
+    new = lambda *s: torch.empty(*s, device="cuda")
+    d = [{k: cu(v) for k, v in p.items()} for p in layers]
+    packed = new(lib.dec_packed_w_floats())
+    lib.dec_pack_w((VP * 8)(*[p[k].data_ptr() for p in d for k in ("Wq", "Wo", "W1", "W2")]), packed)
+    tabs = []
+    for p in d:
+        t = new(lib.dec_kv_table_floats(B))
+        lib.dec_pack_kv(p["Kp"], p["Vp"], t, B)
+        tabs.append(t)
+    params = [[p[k] for k in ("bq", "bo", "b1", "b2", "g2", "be2", "g3", "be3")] for p in d]
+    saved = [[new(R0, 64) for _ in range(7)] for _ in range(2)]
+    tp = new(R0, 64)
+    tg, q_, nw_, nb_ = cu(tgt), cu(qp), cu(nw), cu(nb)
+    sites = (U32 * 8)(*range(8))
+    lib.dec_fwd(tg, q_, packed, (VP * 2)(*[t.data_ptr() for t in tabs]), (VP * 16)(*[t.data_ptr() for ps in params for t in ps]), nw_, nb_,
+                (VP * 14)(*[t.data_ptr() for sv in saved for t in sv]), tp, B, Lq, sites, 0, 1.0, None)
+    close(tp, tp_ref, 2e-5, "tp_map")
+
+    dtp = cu(wout)
+    dtgt1, dtgt0, dqp = new(R0, 64), torch.ones(R0, 64, device="cuda"), new(R0, 64)
+    gnorm = [torch.zeros(64, device="cuda") for _ in range(2)]
+    for li in (1, 0):
+        dY = [new(R0, 64) for _ in range(4)]
+        kvpart, lnpart = new(lib.dec_bwd_kvpart_floats(B, Lq)), new(lib.dec_bwd_lnpart_floats(B, Lq))
+        lib.dec_bwd(li, None if li == 1 else dtgt1, dtp, packed, tabs[li], (VP * 8)(*[t.data_ptr() for t in params[li]]), nw_,
+                    (VP * 7)(*[t.data_ptr() for t in saved[li]]), dtgt1 if li == 1 else dtgt0, 0 if li == 1 else 1, dqp, 0 if li == 1 else 1,
+                    (VP * 4)(*[t.data_ptr() for t in dY]), kvpart, lnpart, B, Lq, (U32 * 4)(*range(4 * li, 4 * li + 4)), 0, 1.0, None)
+        gl = [torch.zeros(64, device="cuda") for _ in range(4)]
+        lib.dec_ln_final(lnpart, B, Lq, (VP * 6)(*[t.data_ptr() for t in gl + gnorm]))
+        dK, dV = new(Rt, 64), new(Rt, 64)
+        lib.attn_kv_final(kvpart, Lq // 32, B, dK, dV, 0)
+        p = layers[li]
+        close(dK, p["Kp"].grad, 5e-5, f"dKp{li}")
+        close(dV, p["Vp"].grad, 5e-5, f"dVp{li}")
+        for gi, k in zip(gl, ("g2", "be2", "g3", "be3")):
+            close(gi, p[k].grad, 5e-5, f"d{k}{li}")
+        qin, _, c, _, t2, hd, _ = saved[li]
+        for dy, x, w, b_ in zip(dY, (qin, c, t2, hd), ("Wq", "Wo", "W1", "W2"), ("bq", "bo", "b1", "b2")):
+            close(dy.double().t() @ x.double(), p[w].grad, 5e-5, f"d{w}{li}")
+            close(dy.double().sum(0), p[b_].grad, 5e-5, f"d{b_}{li}")
+    close(gnorm[0], nw.grad, 5e-5, "d decoder.norm.weight")
+    close(gnorm[1], nb.grad, 5e-5, "d decoder.norm.bias")
+    close(dtgt0 - 1.0, tgt.grad, 5e-5, "dtgt (accumulated onto ones)")
+    close(dqp, qp.grad, 5e-5, "dqp")
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_module_fused_decoder_equals_per_op_decoder(p_drop):
+    """Same weights, inputs, dropout seed: the fused decoder and the per-op launches share the hash masks, so outputs and all
+    gradients agree to summation order."""
+    from tatt_amd.model.tsrn import TSRN_TL_TRANS
+    B, K = 3, 37
+    res = []
+    for fused in (True, False):
+        m = TSRN_TL_TRANS(text_embedding=K)
+        m.load_state_dict(procgen.fill_state(m.state_dict(), seed=1))
+        m = m.cuda().train()
+        m.dropout_p = p_drop
+        eng = m.engine()
+        eng.dec_fused = fused
+        hr, lr, tp = procgen.make_inputs(B, K, seed=3)
+        sr, ctx = eng.forward(lr.cuda(), tp.cuda(), True, 5)
+        G = {n: torch.zeros_like(p) for n, p in m.named_parameters()}
+        gen = torch.Generator().manual_seed(0)
+        eng.backward(ctx, torch.randn(sr.shape, generator=gen).cuda(), G)
+        torch.cuda.synchronize()
+        res.append((sr, ctx["tp_map"], G))
+    (sr_a, tp_a, Ga), (sr_b, tp_b, Gb) = res
+    close(tp_a, tp_b, 1e-5, "tp_map")
+    close(sr_a, sr_b, 1e-5, "sr")
+    from tatt_amd.engine import unused_param
+    for n in Ga:
+        if unused_param(n) or n == "stn_head.stn_fc1.0.bias":     # a bias in front of a training-mode BatchNorm: its true gradient is 0
+            continue
+        r = rel_l2(Ga[n].cpu().numpy(), Gb[n].cpu().numpy())
+        assert r < 2e-3, (n, r)        # B = 3 in training mode: summation-order noise is amplified; a wrong mask gives O(1)
