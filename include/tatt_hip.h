@@ -193,8 +193,8 @@ int tatt_attn_kv_final(const float* part, int nchunk, int B, float* dK, float* d
  *   tatt_dec_bwd: one layer (1 first, then 0).  dt3_in: gradient wrt the layer's output from the layer above (NULL for layer 1);
  *       dtp: gradient of tp_map; dtgt / dqp (+)= the gradients wrt the layer's input and query_pos; dY = host array [4] of [B*Lq][64]
  *       outputs (dQ, d attn-out, d hidden, d ffn-out), the left operands of the four weight gradients dY^T X with X = saved qin,
- *       context, LayerNorm2 output, dropped hidden (tatt_tn_small_group); kvpart (tatt_dec_bwd_kvpart_floats): per-32-token partials
- *       of dKp / dVp for tatt_attn_kv_final(nchunk = Lq/32); lnpart (tatt_dec_bwd_lnpart_floats): per-wave partials of the
+ *       context, LayerNorm2 output, dropped hidden (tatt_tn_small_group); kvpart (tatt_dec_bwd_kvpart_floats): per-128-token partials
+ *       of dKp / dVp for tatt_attn_kv_final(nchunk = Lq/128); lnpart (tatt_dec_bwd_lnpart_floats): per-workgroup partials of the
  *       LayerNorm weight / bias gradients for tatt_dec_ln_final (grads = host array [6]: norm2.weight, norm2.bias, norm3.weight,
  *       norm3.bias, decoder.norm.weight, decoder.norm.bias; each +=). */
 size_t tatt_dec_packed_w_floats(void);

@@ -69,6 +69,9 @@ __device__ __forceinline__ void t_load(T32& x, const float* __restrict__ p, int 
     }
 }
 __device__ __forceinline__ void t_store(const T32& x, float* __restrict__ p, int hi) {
+#ifdef DEC_KO_STORE
+  if (x.b[0][0] != 12345.678f) return;
+#endif
 #pragma unroll
   for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -82,8 +85,12 @@ __device__ __forceinline__ void mm64(T32& acc, const float4* __restrict__ Wf, in
   for (int obk = 0; obk < 2; ++obk)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+#ifdef DEC_KO_WLOAD
+      const float4 a0 = make_float4(lane * 0.01f, 0.1f, 0.2f, 0.3f), a1 = make_float4(0.1f, lane * 0.02f, 0.2f, 0.3f);
+#else
       const float4 a0 = Wf[((0 * 2 + obk) * 4 + g) * 64 + lane];
       const float4 a1 = Wf[((1 * 2 + obk) * 4 + g) * 64 + lane];
+#endif
       acc.b[0] = mfma(a0.x, x.b[obk][g * 4 + 0], acc.b[0]);
       acc.b[1] = mfma(a1.x, x.b[obk][g * 4 + 0], acc.b[1]);
       acc.b[0] = mfma(a0.y, x.b[obk][g * 4 + 1], acc.b[0]);
@@ -281,10 +288,10 @@ __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
 // gradients that contract over tokens are produced as follows:
 //   * dY operands of the four weight gradients (dQ, d attn-out, d hidden, d ffn-out) are stored; tatt_tn_small_group sums dY^T X;
 //   * dK / dV of the attention: per wave, P (dropped) / dS and the context gradient / Q are transposed through a wave-private LDS
-//     tile and multiplied on the matrix core, out[key][feature] over the wave's 32 tokens; stored as per-wave partials in the layout
-//     attn_bwd_final sums ([chunk][2][B*26][64]);
+//     tile and multiplied on the matrix core, out[key][feature] over the wave's 32 tokens; the four waves' partials are summed
+//     through LDS and stored once per workgroup in the layout attn_bwd_final sums ([chunk][2][B*26][64], chunk = 128 tokens);
 //   * LayerNorm weight / bias gradients: per-lane products reduced over the 32 token lanes by recursive halving (31 exchanges per
-//     64-vector), one partial row per wave; dec_ln_final sums the rows.
+//     64-vector), summed over the workgroup's waves through LDS; dec_ln_final sums the per-workgroup rows.
 struct DecBwdArgs {
   DecLayer L;
   const float* dt3_in;     // gradient arriving at the layer's output from the layer above (NULL: none)
@@ -295,8 +302,8 @@ struct DecBwdArgs {
   float* dqp;              // gradient wrt query_pos
   int dqp_acc;
   float* dY[4];            // dQ, da, dh, df
-  float* kvpart;           // [Lq/32][2][B*26][64]
-  float* lnpart;           // [R0/32][6][64]: d norm2.weight, d norm2.bias, d norm3.weight, d norm3.bias, d decoder.norm.weight, .bias
+  float* kvpart;           // [Lq/128][2][B*26][64]: one partial per workgroup (128 tokens)
+  float* lnpart;           // [R0/128][6][64]: d norm2.weight, d norm2.bias, d norm3.weight, d norm3.bias, d decoder.norm.weight, .bias
   int Lq, B;
   uint32_t thresh;
   float scale;
@@ -403,7 +410,8 @@ __device__ __forceinline__ void tile_put(float* tB, const f32x16& x, int lane, i
 }
 
 __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs A) {
-  __shared__ __attribute__((aligned(16))) float tiles[4][3][32 * TS];
+  __shared__ __attribute__((aligned(16))) float tiles[4][3][32 * TS];   // 13,824 floats; reused at the end for the 4 x 3,328 dK / dV partials
+  __shared__ float lnred[4][6 * 64];
   const int lane = threadIdx.x & 63, hi = lane >> 5, wv = threadIdx.x >> 6;
   const uint32_t row = (uint32_t)(blockIdx.x * 128 + wv * 32 + (lane & 31));
   const int b = (int)(row / (uint32_t)A.Lq), q = (int)(row - (uint32_t)b * (uint32_t)A.Lq);
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs A) {
   const uint32_t sd = A.seed_dev ? A.seed_dev[0] * 0x85EBCA77u : 0u;
   const DecLayer& L = A.L;
   const float4* __restrict__ kvb = L.kv + (long)b * KV_SLOTS * 64;
-  float* lnp = A.lnpart + (long)(blockIdx.x * 4 + wv) * 6 * 64;
+  float* lnp = lnred[wv];
   float* tA = tiles[wv][0];
   float* tB1 = tiles[wv][1];
   float* tB2 = tiles[wv][2];
@@ -549,23 +557,6 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs A) {
     tok_contract(dKa.b[ob], ds, tA, tB2, hh, lane, hi);            // dK[key][f] += dS^T Q   (x 1/4 below)
   }
   t_store(dQ, A.dY[0] + ro, hi);
-  // dK / dV partial of this wave: registers <-> keys, lane % 32 <-> feature of the block
-  {
-    const int chunk = q >> 5;                                      // wave-uniform: a wave's 32 tokens share b and q / 32
-    const long n = (long)A.B * S * E;
-    float* pv = A.kvpart + ((long)chunk * 2 + 0) * n + (long)b * S * E;
-    float* pk = A.kvpart + ((long)chunk * 2 + 1) * n + (long)b * S * E;
-#pragma unroll
-    for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = key_of(i, hi);
-        if (key < S) {
-          pv[key * E + ob * 32 + (lane & 31)] = dVa.b[ob][i];
-          pk[key * E + ob * 32 + (lane & 31)] = 0.25f * dKa.b[ob][i];
-        }
-      }
-  }
   // ---- query projection backward
   t_zero(g);
   mm64(g, L.Wf + 4 * 1024, lane, dQ);                              // dqin = Wq^T dQ
@@ -589,17 +580,64 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs A) {
       for (int i = 0; i < 16; ++i) g.b[ob][i] += x.b[ob][i];
   }
   t_store(g, A.dqp + ro, hi);
+  // ---- the workgroup's partials: dK / dV (registers <-> keys, lane % 32 <-> feature of the block) and the LayerNorm rows of its four
+  // waves are summed through LDS (the transpose tiles are free now) and stored once per workgroup
+  __syncthreads();
+  {
+    float* red = &tiles[0][0][0] + wv * (2 * S * E);
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = key_of(i, hi);
+        if (key < S) {
+          red[key * E + ob * 32 + (lane & 31)] = dVa.b[ob][i];
+          red[(S + key) * E + ob * 32 + (lane & 31)] = 0.25f * dKa.b[ob][i];
+        }
+      }
+  }
+  __syncthreads();
+  {
+    const float* red = &tiles[0][0][0];
+    const int chunk = q >> 7;                                      // workgroup-uniform: its 128 tokens share b and q / 128
+    const long n = (long)A.B * S * E;
+    float* pv = A.kvpart + ((long)chunk * 2) * n + (long)b * S * E;
+    for (int idx = threadIdx.x; idx < 2 * S * E; idx += 256) {
+      const float v = (red[idx] + red[2 * S * E + idx]) + (red[4 * S * E + idx] + red[6 * S * E + idx]);
+      const int which = idx >= S * E;
+      pv[(long)which * n + (idx - which * S * E)] = v;
+    }
+    float* lo = A.lnpart + (long)blockIdx.x * 6 * 64;
+    for (int idx = threadIdx.x; idx < 6 * 64; idx += 256)
+      lo[idx] = (lnred[0][idx] + lnred[1][idx]) + (lnred[2][idx] + lnred[3][idx]);
+  }
 }
 
 // LayerNorm parameter gradients: column sums of the per-wave partial rows.  part [nblk][nvec][64]; out[v] (+)= sum over blk.
 struct LnFinalArgs {
   float* out[6];
 };
-__global__ void dec_ln_final(const float* __restrict__ part, int nblk, int nvec, LnFinalArgs o) {
-  __shared__ float red[256];
-  const int v = blockIdx.y, c = blockIdx.x * 16 + (threadIdx.x & 15);
-  const float s = block16_colsum(part + v * 64, nblk, (long)nvec * 64, c, true, red);
-  if (threadIdx.x < 16) o.out[v][c] += s;
+__global__ __launch_bounds__(1024) void dec_ln_final(const float* __restrict__ part, int nblk, int nvec, LnFinalArgs o) {
+  __shared__ float red[64][17];
+  const int v = blockIdx.y, cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+  const float* p = part + v * 64 + c;
+  const long st = (long)nvec * 64;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = rl;
+  for (; b + 192 < nblk; b += 256) {
+    s0 += p[(long)b * st];
+    s1 += p[(long)(b + 64) * st];
+    s2 += p[(long)(b + 128) * st];
+    s3 += p[(long)(b + 192) * st];
+  }
+  for (; b < nblk; b += 64) s0 += p[(long)b * st];
+  red[rl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0) {
+    float t = 0.f;
+    for (int j = 0; j < 64; ++j) t += red[j][cl];
+    o.out[v][c] += t;
+  }
 }
 
 // ---- operand packs ---------------------------------------------------------------------------------------------------------
@@ -665,8 +703,8 @@ extern "C" {
 
 size_t tatt_dec_packed_w_floats(void) { return (size_t)16 * 4096; }
 size_t tatt_dec_kv_table_floats(int B) { return (size_t)B * KV_SLOTS * 64 * 4; }
-size_t tatt_dec_bwd_kvpart_floats(int B, int Lq) { return (size_t)(Lq / 32) * 2 * B * S * E; }
-size_t tatt_dec_bwd_lnpart_floats(int B, int Lq) { return (size_t)B * (Lq / 32) * 6 * 64; }
+size_t tatt_dec_bwd_kvpart_floats(int B, int Lq) { return (size_t)(Lq / 128) * 2 * B * S * E; }
+size_t tatt_dec_bwd_lnpart_floats(int B, int Lq) { return (size_t)B * (Lq / 128) * 6 * 64; }
 
 int tatt_dec_pack_w(const float* const* W, float* packed, hipStream_t st) {
   TATT_CHECK_ARG(W && packed && (((uintptr_t)packed) & 15) == 0, "tatt_dec_pack_w: bad arguments");
@@ -754,7 +792,7 @@ int tatt_dec_ln_final(const float* lnpart, int B, int Lq, float* const* grads, h
     TATT_CHECK_ARG(grads[i], "tatt_dec_ln_final: gradient %d missing", i);
     o.out[i] = grads[i];
   }
-  hipLaunchKernelGGL(dec_ln_final, dim3(4, 6), dim3(256), 0, st, lnpart, B * (Lq / 32), 6, o);
+  hipLaunchKernelGGL(dec_ln_final, dim3(4, 6), dim3(1024), 0, st, lnpart, B * (Lq / 128), 6, o);
   TATT_LAUNCH_CHECK("dec_ln_final");
   return TATT_OK;
 }

@@ -621,7 +621,7 @@ class Engine:
                                                                             tr + "decoder.norm.weight", tr + "decoder.norm.bias")]))
             Kp, Vp, _ = dec_kv[li]
             dKp, dVp = self.new(Rt, 64), self.new(Rt, 64)
-            L.attn_kv_final(kvpart, Lq // 32, B, dKp, dVp, 0)
+            L.attn_kv_final(kvpart, Lq // 128, B, dKp, dVp, 0)
             W = P[d + "multihead_attn.in_proj_weight"]
             dW, db = G[d + "multihead_attn.in_proj_weight"], G[d + "multihead_attn.in_proj_bias"]
             qin, _, c, _, t2, hd, _ = saved[li]

@@ -12,7 +12,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtatt_hip.so")
+LIB_PATH = os.environ.get("TATT_LIB") or os.path.join(_HERE, "libtatt_hip.so")     # TATT_LIB: another build of the same library (A/B runs)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tatt_hip.h")
 
 _CT = {

@@ -100,7 +100,7 @@ def test_dec_fused_fwd_bwd_vs_fp64(B, Lq):
         gl = [torch.zeros(64, device="cuda") for _ in range(4)]
         lib.dec_ln_final(lnpart, B, Lq, (VP * 6)(*[t.data_ptr() for t in gl + gnorm]))
         dK, dV = new(Rt, 64), new(Rt, 64)
-        lib.attn_kv_final(kvpart, Lq // 32, B, dK, dV, 0)
+        lib.attn_kv_final(kvpart, Lq // 128, B, dK, dV, 0)
         p = layers[li]
         close(dK, p["Kp"].grad, 5e-5, f"dKp{li}")
         close(dV, p["Vp"].grad, 5e-5, f"dVp{li}")
@@ -121,7 +121,7 @@ def test_module_fused_decoder_equals_per_op_decoder(p_drop):
     """Same weights, inputs, dropout seed: the fused decoder and the per-op launches share the hash masks, so outputs and all
     gradients agree to summation order."""
     from tatt_amd.model.tsrn import TSRN_TL_TRANS
-    B, K = 3, 37
+    B, K = 8, 37
     res = []
     for fused in (True, False):
         m = TSRN_TL_TRANS(text_embedding=K)
@@ -145,4 +145,4 @@ def test_module_fused_decoder_equals_per_op_decoder(p_drop):
         if unused_param(n) or n == "stn_head.stn_fc1.0.bias":     # a bias in front of a training-mode BatchNorm: its true gradient is 0
             continue
         r = rel_l2(Ga[n].cpu().numpy(), Gb[n].cpu().numpy())
-        assert r < 2e-3, (n, r)        # B = 3 in training mode: summation-order noise is amplified; a wrong mask gives O(1)
+        assert r < 2e-5, (n, r)        # measured 2.8e-6 at B = 8 (at B = 3 training mode amplifies summation-order noise to 2e-3)
