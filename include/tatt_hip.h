@@ -70,8 +70,10 @@ int tatt_gemm_cat(const float* A, const float* A2, int ksplit, const float* B, f
  * same buffer by WcT[Cin][64] = W_c transposed, which tatt_gru_unfold_grad reads: Wf buffers hold 256*Cin floats) / bf[192] for
  * n <= 16 blocks in one launch (HOST arrays of length n; Wih / bih hold 2n pointers: forward, reverse per block);
  * tatt_gru_unfold_grad adds the gradient of (Wf, bf) onto the reference's parameters: dW_ih += dWf W_c^T + dbf b_c^T,
- * db_ih += dbf, dW_c += W_ih^T dWf, db_c += W_ih^T dbf. */
+ * db_ih += dbf, dW_c += W_ih^T dWf, db_c += W_ih^T dbf; tatt_gru_unfold_grad_group: the same for n <= 16 blocks in one launch (HOST arrays
+ * of length n; Wih / dWih / dbih hold 2n pointers). */
 int tatt_gru_fold_w(int n, const float* const* Wc, const float* const* bc, const float* const* Wih, const float* const* bih, float* const* Wf, float* const* bf, const int* Cin, hipStream_t stream);
+int tatt_gru_unfold_grad_group(int n, const float* const* dWf, const float* const* dbf, const float* const* WcT, const float* const* bc, const float* const* Wih, float* const* dWih, float* const* dbih, float* const* dWc, float* const* dbc, const int* Cin, hipStream_t stream);
 int tatt_gru_unfold_grad(const float* dWf, const float* dbf, const float* WcT, const float* bc, const float* Wih_f, const float* Wih_b, float* dWih_f, float* dWih_b, float* dbih_f, float* dbih_b, float* dWc, float* dbc, int Cin, hipStream_t stream);
 
 /* Weight + bias gradient of a Linear / 1x1 conv with a small output (M <= 96, N <= 64): dW[M,N] += dY[R,M]^T X[R,N],

@@ -56,7 +56,17 @@ struct UnfoldArgs {
   int Cin;
 };
 
-__global__ __launch_bounds__(256) void gru_unfold_grad_k(UnfoldArgs u) {
+struct UnfoldGroup {
+  UnfoldArgs u[FOLD_MAX];
+};
+
+__device__ __forceinline__ void gru_unfold_body(const UnfoldArgs& u);
+
+__global__ __launch_bounds__(256) void gru_unfold_grad_k(UnfoldArgs u) { gru_unfold_body(u); }
+// blockIdx.y = block of the group: the ten GruBlocks of a backward pass in ONE launch (each is a latency-bound handful of workgroups)
+__global__ __launch_bounds__(256) void gru_unfold_grad_group_k(UnfoldGroup g) { gru_unfold_body(g.u[blockIdx.y]); }
+
+__device__ __forceinline__ void gru_unfold_body(const UnfoldArgs& u) {
   const int Cin = u.Cin;
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i < 192 * 64) {  // dW_ih[j][m] += sum_c dWf[j][c] Wc[m][c] + dbf[j] bc[m]
@@ -136,6 +146,27 @@ int tatt_gru_unfold_grad(const float* dWf, const float* dbf, const float* WcT, c
   UnfoldArgs u{dWf, dbf, WcT, bc, {Wih_f, Wih_b}, {dWih_f, dWih_b}, {dbih_f, dbih_b}, dWc, dbc, Cin};
   hipLaunchKernelGGL(gru_unfold_grad_k, dim3(cdiv(192 * 64 + 192 + 64 * Cin + 64, 256)), dim3(256), 0, st, u);
   TATT_LAUNCH_CHECK("gru_unfold_grad");
+  return TATT_OK;
+}
+
+// The same for n <= 16 GruBlocks in one launch.  HOST arrays of length n (Wih / dWih / dbih: 2n entries, forward then reverse per block).
+int tatt_gru_unfold_grad_group(int n, const float* const* dWf, const float* const* dbf, const float* const* WcT, const float* const* bc,
+                               const float* const* Wih, float* const* dWih, float* const* dbih, float* const* dWc, float* const* dbc,
+                               const int* Cin, hipStream_t st) {
+  TATT_CHECK_ARG(n > 0 && n <= FOLD_MAX && dWf && dbf && WcT && bc && Wih && dWih && dbih && dWc && dbc && Cin,
+                 "tatt_gru_unfold_grad_group: 1..%d blocks, non-null arrays", FOLD_MAX);
+  UnfoldGroup g;
+  memset(&g, 0, sizeof(g));
+  int mx = 0;
+  for (int i = 0; i < n; ++i) {
+    TATT_CHECK_ARG(dWf[i] && dbf[i] && WcT[i] && bc[i] && Wih[2 * i] && Wih[2 * i + 1] && dWih[2 * i] && dWih[2 * i + 1] && dbih[2 * i] &&
+                       dbih[2 * i + 1] && dWc[i] && dbc[i] && Cin[i] > 0 && Cin[i] % 4 == 0, "tatt_gru_unfold_grad_group: bad block %d", i);
+    g.u[i] = UnfoldArgs{dWf[i], dbf[i], WcT[i], bc[i], {Wih[2 * i], Wih[2 * i + 1]}, {dWih[2 * i], dWih[2 * i + 1]},
+                        {dbih[2 * i], dbih[2 * i + 1]}, dWc[i], dbc[i], Cin[i]};
+    if (Cin[i] > mx) mx = Cin[i];
+  }
+  hipLaunchKernelGGL(gru_unfold_grad_group_k, dim3(cdiv(192 * 64 + 192 + 64 * mx + 64, 256), n), dim3(256), 0, st, g);
+  TATT_LAUNCH_CHECK("gru_unfold_grad_group");
   return TATT_OK;
 }
 

@@ -485,8 +485,8 @@ class Engine:
                     *self._seqmap(B, H, W, vertical))
         Wf, _, WcT = self._gru_fold()[pre]
         Cin = Wf.shape[1]
-        tmp = self.zeros(192 * Cin + 192)                     # gradient of the composed (Wf, bf); unfolded onto W_ih, W_c, biases below
-        dWf, dbf = tmp[:192 * Cin], tmp[192 * Cin:]
+        tmp = self._gru_gtmp[pre]                             # (zeroed) gradient of the composed (Wf, bf); unfolded onto W_ih, W_c, biases
+        dWf, dbf = tmp[:192 * Cin], tmp[192 * Cin:]           # by ONE grouped launch for all GruBlocks at the end of the SRB stage
         wg = []                                               # all streaming weight gradients of the block: one grouped launch
         for d, sfx in enumerate(["", "_reverse"]):
             gi_d, ghn_d, hp_d = dgi.view(-1)[96 * d:], dghn.view(-1)[32 * d:], hprev.view(-1)[32 * d:]
@@ -495,12 +495,7 @@ class Engine:
             for s, (x, _, _) in enumerate(inputs):
                 wg.append((gi_d, x, dWf[96 * d * Cin + 64 * s:], dbf[96 * d:] if s == 0 else None, R, 96, 64, 192, None, Cin))
         self.linear_dwb_group(wg)                             # queued before the input gradients below may update a dx in place
-        sfxs = ("", "_reverse")
-        self._wgrad(lambda ws: L.gru_unfold_grad(dWf, dbf, WcT, P[pre + "conv1.bias"],
-                                                 *[P[pre + "gru.weight_ih_l0" + x] for x in sfxs],
-                                                 *[G[pre + "gru.weight_ih_l0" + x] for x in sfxs],
-                                                 *[G[pre + "gru.bias_ih_l0" + x] for x in sfxs],
-                                                 G[pre + "conv1.weight"], G[pre + "conv1.bias"], Cin), [tmp])
+        self._gru_unfold.append((pre, dWf, dbf, WcT, Cin))
         for _, dx, _ in inputs:
             self._guard(dx)
         two = len(inputs) > 1
@@ -961,12 +956,31 @@ class Engine:
         user_stage = on_stage
         self._w_keep, self._w_pending, self._w_defer = [], set(), []   # nothing may survive from a pass that raised half way
 
+        def finish_unfold():
+            """The gradients of the composed GRU input projections (Wf, bf) of ALL GruBlocks -> W_ih, W_c, biases, one launch
+            (tatt_gru_unfold_grad_group) on the main stream, after a join: it reads what the grouped weight-gradient kernels of
+            both weight-gradient streams accumulated."""
+            un, n_ = self._gru_unfold, len(self._gru_unfold)
+            if not n_:
+                return
+            VP, sfxs = ctypes.c_void_p, ("", "_reverse")
+            arr = lambda ts: (VP * len(ts))(*[t.data_ptr() for t in ts])
+            L.gru_unfold_grad_group(n_, arr([u[1] for u in un]), arr([u[2] for u in un]), arr([u[3] for u in un]), arr([P[u[0] + "conv1.bias"] for u in un]),
+                                    arr([P[u[0] + "gru.weight_ih_l0" + x] for u in un for x in sfxs]),
+                                    arr([G[u[0] + "gru.weight_ih_l0" + x] for u in un for x in sfxs]),
+                                    arr([G[u[0] + "gru.bias_ih_l0" + x] for u in un for x in sfxs]), arr([G[u[0] + "conv1.weight"] for u in un]),
+                                    arr([G[u[0] + "conv1.bias"] for u in un]), (ctypes.c_int * n_)(*[u[4] for u in un]))
+            self._gru_unfold = []
+
         def on_stage(name):                                   # a bucket is complete only once its weight gradients have landed
             if user_stage is not None:
                 self._w_join()
+                if name == "srbs":
+                    finish_unfold()
                 user_stage(name)
             elif name == "infogen":                           # end of the pass: the optimiser reads every gradient
                 self._w_join()
+                finish_unfold()
             else:
                 self._w_flush()
 
@@ -1003,6 +1017,13 @@ class Engine:
         on_stage("tail")
 
         # ---- SRBs, last to first ----------------------------------------------------------------------------------
+        fold = self._gru_fold()
+        sizes = {pre: 192 * fold[pre][0].shape[1] + 192 for pre in fold}
+        gbuf, o = self.zeros(sum(sizes.values())), 0          # one memset for the (Wf, bf) gradients of all GruBlocks
+        self._gru_gtmp, self._gru_unfold = {}, []
+        for pre, n_ in sizes.items():
+            self._gru_gtmp[pre] = gbuf[o:o + n_]
+            o += n_
         dtp = self.new(R0, 64)
         first_tp = True
         for i in reversed(range(m.srb_nums)):

@@ -288,6 +288,53 @@ def test_full_batch_properties(B):
         assert rel_l2((2 * G1[n]).cpu().numpy(), G2[n].cpu().numpy()) < 1e-5, n
 
 
+def test_config5_at_its_own_size_B64_K2448():
+    """BASELINE config 5 (K = 2448 text-prior classes) at the per-GPU batch it is quoted on: fc_in is a [1664,2448] x [2448,64] product
+    and its weight gradient a 1664-row reduction into [64,2448].  Text-branch stages against the fp64 oracle, the engine's own fc_in
+    forward / weight-gradient launches at that size against fp64 products, and finiteness + linearity of the whole backward pass."""
+    B, K = 64, 2448
+    state = make_state(K, seed=2)
+    m = build(K, seed=2).train()
+    hr, lr, tp = procgen.make_inputs(B, K, seed=6)
+    eng = m.engine()
+    sr, ctx = eng.forward(lr.cuda(), tp.cuda(), True, 0, p_drop=0.0)
+    assert torch.isfinite(sr).all()
+    P = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in state.items()}
+    inter = {}
+    with torch.no_grad():
+        sr_o = R.tsrn_forward(P, lr.double(), tp.double(), training=True, inter=inter, fused_rnn=True)
+    st = stages(ctx, B)
+    for k in ["memory", "query_pos", "tp_map", "block2"]:
+        r = rel_l2(st[k].cpu().numpy(), inter[k].detach().numpy())
+        assert r < 2e-5, f"{k}: {r:.3e}"
+    assert float((sr.cpu() - sr_o).abs().max()) < 5e-5
+    # fc_in at 1664 rows: forward and dW / db through the engine's launches
+    tpr, t0 = ctx["tp"][0], ctx["tp"][1]
+    W, b_ = state["infoGen.fc_in.weight"].double(), state["infoGen.fc_in.bias"].double()
+    ref = tpr.cpu().double() @ W.t() + b_
+    assert rel_l2(t0.cpu().numpy(), ref.numpy()) < 2e-5
+    g = torch.Generator().manual_seed(3)
+    dt0 = torch.randn(B * 26, 64, generator=g)
+    dW, db = torch.zeros(64, K, device="cuda"), torch.zeros(64, device="cuda")
+    eng._w_keep, eng._w_pending, eng._w_defer = [], set(), []
+    dt0c = dt0.cuda()
+    eng.linear_dwb(dt0c, tpr, dW, db, B * 26, 64, K)
+    eng._w_join()
+    torch.cuda.synchronize()
+    assert rel_l2(dW.cpu().numpy(), (dt0.double().t() @ tpr.cpu().double()).numpy()) < 5e-5
+    assert rel_l2(db.cpu().numpy(), dt0.double().sum(0).numpy()) < 5e-5
+    # whole backward pass: finite, linear in dsr
+    d = torch.randn_like(sr)
+    G1 = {n: torch.zeros_like(q) for n, q in m.named_parameters()}
+    G2 = {n: torch.zeros_like(q) for n, q in m.named_parameters()}
+    eng.backward(ctx, d, G1)
+    eng.backward(ctx, 2 * d, G2)
+    for n, q in G1.items():
+        assert torch.isfinite(q).all(), n
+    for n in ["infoGen.fc_in.weight", "infoGen.fc_in.bias", "infoGen.transformer.decoder.layers.0.linear1.weight", "block4.conv2.weight"]:
+        assert rel_l2((2 * G1[n]).cpu().numpy(), G2[n].cpu().numpy()) < 1e-5, n
+
+
 def test_eval_matches_oracle_B16():
     """BASELINE config 1 shape (B=16 eval) against the oracle."""
     B = 16
