@@ -463,11 +463,11 @@ class Engine:
         Wf, bf, _ = self._gru_fold()[pre]
         Cin = Wf.shape[1]
         assert Cin == 64 * len(inputs)
+        out = self.new(R, 64)
+        sv = self.new(R, 2, 4, 32) if save else None
         gi = self.new(R, 192)
         self.L.gemm_cat(inputs[0], inputs[1] if len(inputs) > 1 else None, 64, Wf, gi, None, 0, bf, R, 192, Cin, 64, Cin, 1, 192, 0,
                         0, 0, self.pl)
-        out = self.new(R, 64)
-        sv = self.new(R, 2, 4, 32) if save else None
         self.L.gru32_fwd(gi, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], P[pre + "gru.bias_hh_l0"],
                          P[pre + "gru.bias_hh_l0_reverse"], out, sv, *self._seqmap(B, H, W, vertical))
         if save:

@@ -695,3 +695,4 @@ def test_gemm_cat_bnbwd_matches_separate_batchnorm_backward():
     close(dx, x.grad, 5e-5, "dx")
     close(dga, ga.grad, 5e-5, "dgamma")
     close(dbe, be.grad, 5e-5, "dbeta")
+
