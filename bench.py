@@ -272,7 +272,7 @@ def main():
               "rank_ms_per_step_max": round(max(dts) / a.steps * 1e3, 3),
               "allreduce_ms_exposed": round(trainer.exposed_comm_ms(), 4), "grad_bytes_per_step": int(trainer.n) * 4,
               "buckets": [int(b - a_) * 4 for a_, b in trainer.bucket_range]}
-    trainer.eng.check_rpe_chain()                    # the single-launch RPE chains report timed-out waits in a flag word: fail loudly
+    trainer.check_chains()                           # the single-launch recurrences (RPE, LSTM) report timed-out waits in a flag word: fail loudly
     loss = float(per.mean().item()) * 100
     if not (loss == loss and loss < 1e6):
         raise SystemExit(f"non-finite training loss {loss}")

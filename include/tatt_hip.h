@@ -268,6 +268,14 @@ int tatt_crnn_prep(const float* x, float* y, int B, int Ctot, int H, int W, int 
 int tatt_maxpool_gen_fwd(const float* x, float* y, int B, int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW, hipStream_t stream);
 int tatt_linear_f64(const float* x, long ldx, const float* Wt, const float* bias, float* out, long ldo, int R, int N, int K, hipStream_t stream);
 int tatt_lstm256_step_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, const float* hprev, const float* cprev, float* hout, float* cout, float* out, float* save, int s, int T, int B, hipStream_t stream);
+/* The T steps of one nn.LSTM(., 256, bidirectional) (model/crnn/crnn.py:10,:19-21) as ONE launch of persistent workgroups, forward
+ * and BPTT: a chain = (16 batch rows, direction) runs inside one XCD's L2 (32 workgroups x 8 hidden units, W_hh slice in registers,
+ * flag hand-over as tatt_rpe_chain_fwd); B <= 128, device as tatt_rpe_chain_supported().  gi / out / save / dgates / whhT exactly as the
+ * step entry points below (h_0 = c_0 = 0; the carried dc is internal).  sync: tatt_lstm256_chain_sync_words() uint32, zeroed once by
+ * the caller, one buffer per concurrently running call; sync[1] != 0 = a bounded wait gave up (sticky; outputs NaN from there on). */
+size_t tatt_lstm256_chain_sync_words(void);
+int tatt_lstm256_chain_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* out, float* save, int T, int B, uint32_t* sync, hipStream_t stream);
+int tatt_lstm256_chain_bwd(const float* save, const float* whhT, const float* dout, float* dgates, int T, int B, uint32_t* sync, hipStream_t stream);
 /* Backward pieces of the CRNN student (autograd of the modules above).  tatt_lstm256_step_bwd: BPTT step s (call with
  * s = T-1 .. 0); save [T*B][2][5][256] is what tatt_lstm256_step_fwd stored (i, f, g, o, c), whhT [2][256][1024] = W_hh^T
  * per direction (tatt_transpose), dout = d(out), dgates [T*B][2048] receives the pre-activation gate gradients (read back by

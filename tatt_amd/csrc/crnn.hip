@@ -287,6 +287,226 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+// ---- the whole recurrence of one nn.LSTM(., 256, bidirectional) as ONE launch (tatt_lstm256_chain_fwd / _bwd) --------------------
+// Same scheme as the recurrent positional encoding's chains (gru.hip, rpe_chain_fwd): the batch rows are independent, so a chain =
+// (block of 16 rows, direction) lives inside ONE XCD's L2: 32 persistent workgroups, each owning 8 hidden units (their 32 gate
+// columns of W_hh, or 8 rows of W_hh^T in the backward pass, stay in registers for all T steps), exchange the 16 x 256 state through
+// `out` itself (forward) / the gate gradients (backward) with one flag line per reader; a reader polls with one returning L2 atomic
+// and then reads with ordinary first-touch loads.  B = 64 gives 4 row blocks x 2 directions = 8 chains = the 8 XCDs of the chip;
+// any B <= 128 works (group k of XCD x runs chain x + n_xcd * k).  Every wait is bounded; a wait that gives up sets the sticky
+// error word sync[1] and poisons what the chain writes from then on with NaN (the loss shows it).  Hardware assumptions: gru.hip.
+// The workgroups are kept small (forward 256 threads, < 64 registers) so that the chains of the teacher, the student and the RPE,
+// which run at the same time on different streams, always fit on an XCD together: a chain that cannot place all its workgroups
+// would wait for itself until the spin limit.
+constexpr unsigned LSTM_SPIN_LIMIT = 1u << 18;
+constexpr int LSTM_MAX_CHAINS = 16;
+constexpr int LSTM_SYNC_WORDS = 32 * 9 + LSTM_MAX_CHAINS * 1024;   // header (sync[1] sticky error), one ticket line per XCD, per chain [reader 32][writer 32]
+
+__device__ __forceinline__ unsigned lstm_l2_read(unsigned* p) {    // a plain load could be served from the CU's cache for ever
+  unsigned v;
+  const unsigned zero = 0u;
+  asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p), "v"(zero) : "memory");
+  return v;
+}
+// role of this workgroup: chain (row block mh, direction dir) and its 8 hidden units (jb); false: surplus, exit
+__device__ __forceinline__ bool lstm_chain_role(unsigned* sync, int nxcd, int nchains, int& jb, int& mh, int& dir, unsigned*& flags) {
+  __shared__ unsigned s_role[2];
+  if (threadIdx.x == 0) {
+    const int x = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15) % nxcd;  // HW_REG_XCC_ID[3:0]
+    unsigned* line = sync + 32 * (1 + x);
+    const unsigned t = __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    s_role[0] = (unsigned)x + (unsigned)nxcd * (t >> 5);
+    s_role[1] = t & 31;
+  }
+  __syncthreads();
+  const unsigned role = s_role[0];
+  jb = (int)s_role[1];
+  mh = (int)(role >> 1);
+  dir = (int)(role & 1);
+  flags = sync + 32 * 9 + 1024 * (role & (LSTM_MAX_CHAINS - 1));
+  return role < (unsigned)nchains;
+}
+// wait until the 32 owners of this chain have published step `need` (workgroup-uniform result: false = gave up)
+__device__ __forceinline__ bool lstm_wait(unsigned* flags, int jb, unsigned need, unsigned* sync) {
+  for (unsigned it = 0;; ++it) {
+    unsigned f = 0xffffffffu;
+    if (threadIdx.x < 32) f = lstm_l2_read(flags + jb * 32 + threadIdx.x);
+    if (__syncthreads_and(f >= need)) return true;
+    if (it > LSTM_SPIN_LIMIT) {
+      if (threadIdx.x == 0) __hip_atomic_fetch_or(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+__device__ __forceinline__ void lstm_publish(unsigned* flags, int jb, unsigned v) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);          // this thread's stores have reached L2
+  __syncthreads();
+  if (threadIdx.x < 32) *reinterpret_cast<volatile unsigned*>(flags + threadIdx.x * 32 + jb) = v;  // one copy per reader
+}
+
+// gi [T*B][2048] (dir*1024 + gate*256 + j), out [T*B][512] (dir*256 + j), save [T*B][2][5][256] or NULL: as tatt_lstm256_step_fwd.
+__global__ __launch_bounds__(256, 4) void lstm_chain_fwd_k(const float* __restrict__ gi, const float* __restrict__ whh_f,
+                                                           const float* __restrict__ whh_b, const float* __restrict__ bhh_f,
+                                                           const float* __restrict__ bhh_b, float* out, float* __restrict__ save,
+                                                           int T, int B, unsigned* sync, int nxcd) {
+  __shared__ float red[4][16][33];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, q = lane >> 4;
+  int jb, mh, dir;
+  unsigned* flags;
+  if (!lstm_chain_role(sync, nxcd, 2 * ((B + 15) / 16), jb, mh, dir, flags)) return;
+  const float* W = dir ? whh_b : whh_f;
+  const int kbase = wv * 64 + q * 4;      // the four waves split K = 256; lane (i, q): k = kbase + 16 e + 0..3
+  // once for the whole chain: W_hh rows of this workgroup's 32 gate columns (two 16-wide tiles: column i of tile n = gate 2n + i/8, unit i%8)
+  float4 bf[2][4];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const float* pb = W + (long)((2 * n + (i >> 3)) * LH + jb * 8 + (i & 7)) * LH + kbase;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bf[n][e] = *reinterpret_cast<const float4*>(pb + 16 * e);
+  }
+  // gate phase: thread (row wl, unit jj) for tid < 128
+  const int wl = (tid >> 3) & 15, jj = tid & 7, row = mh * 16 + wl, j = jb * 8 + jj;
+  const bool gate = tid < 128 && row < B;
+  const float* bh = dir ? bhh_b : bhh_f;
+  float bg[4] = {0.f, 0.f, 0.f, 0.f};
+  if (gate) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bg[g] = bh[g * LH + j];
+  }
+  const int arow = mh * 16 + i;            // A operand row of this lane
+  const bool aon = arow < B;
+  float cp = 0.f;
+  bool bad = false;
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
+    float g4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gate) {                            // independent of the chain: requested before the wait
+      const float* g_i = gi + ((long)t * B + row) * (8 * LH) + dir * 4 * LH + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) g4[g] = g_i[g * LH] + bg[g];
+    }
+    if (s > 0) {
+      if (!lstm_wait(flags, jb, (unsigned)s, sync)) bad = true;
+      // h of the previous step: rows of `out` written by this XCD's owners, first touched by this CU now
+      float4 af[4];
+      const float* pa = out + ((long)tp * B + arow) * (2 * LH) + dir * LH + kbase;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) af[e] = aon ? *reinterpret_cast<const float4*>(pa + 16 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e].x, bf[n][e].x, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e].y, bf[n][e].y, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e].z, bf[n][e].z, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e].w, bf[n][e].w, acc[n], 0, 0, 0);
+        }
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][4 * q + r][n * 16 + i] = acc[n][r];
+      __syncthreads();
+      if (gate) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) g4[g] += (red[0][wl][g * 8 + jj] + red[1][wl][g * 8 + jj]) + (red[2][wl][g * 8 + jj] + red[3][wl][g * 8 + jj]);
+      }
+    }
+    if (gate) {
+      const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf_(g4[2]), og = sigmoidf_(g4[3]);
+      const float c = fg * cp + ig * gg;
+      const float h = og * tanhf_(c);
+      cp = c;
+      out[((long)t * B + row) * (2 * LH) + dir * LH + j] = bad ? __builtin_nanf("") : h;
+      if (save) {
+        float* sp = save + (((long)t * B + row) * 2 + dir) * 5 * LH + j;
+        sp[0] = ig;
+        sp[LH] = fg;
+        sp[2 * LH] = gg;
+        sp[3 * LH] = og;
+        sp[4 * LH] = c;
+      }
+    }
+    lstm_publish(flags, jb, (unsigned)s + 1u);
+  }
+}
+
+// BPTT chain: as T launches of lstm_step_bwd_k (s = T-1 .. 0).  dgates [T*B][2048] is both the result and the hand-over buffer;
+// the carried dc belongs to one thread for the whole chain (a register).
+__global__ __launch_bounds__(512, 2) void lstm_chain_bwd_k(const float* __restrict__ save, const float* __restrict__ whhT,
+                                                           const float* __restrict__ dout, float* dgates, int T, int B, unsigned* sync,
+                                                           int nxcd) {
+  __shared__ float red[8][16][9];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, q = lane >> 4;
+  int jb, mh, dir;
+  unsigned* flags;
+  if (!lstm_chain_role(sync, nxcd, 2 * ((B + 15) / 16), jb, mh, dir, flags)) return;
+  // once: rows jb*8 .. +7 of W_hh^T (K = 1024 split over the eight waves); columns 8..15 of the 16-wide tile are padding
+  const int kbase = wv * 128 + q * 4;
+  float4 bf[8];
+  {
+    const float* Bt = whhT + ((long)dir * LH + jb * 8 + (i & 7)) * (4 * LH) + kbase;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bf[e] = i < 8 ? *reinterpret_cast<const float4*>(Bt + 16 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int wl = (tid >> 3) & 15, jj = tid & 7, row = mh * 16 + wl, j = jb * 8 + jj;
+  const bool gate = tid < 128 && row < B;
+  const int arow = mh * 16 + i;
+  const bool aon = arow < B;
+  float carry = 0.f;
+  bool bad = false;
+  for (int s = T - 1; s >= 0; --s) {
+    const int t = dir ? T - 1 - s : s;
+    const int tn = dir ? t - 1 : t + 1;   // the step differentiated just before (its gate gradients feed dh)
+    const int tp = dir ? t + 1 : t - 1;   // forward-order predecessor (its c is c_prev of this step)
+    float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f;
+    if (gate) {                            // independent of the chain: requested before the wait
+      dh = dout[((long)t * B + row) * (2 * LH) + dir * LH + j];
+      const float* sp = save + (((long)t * B + row) * 2 + dir) * 5 * LH + j;
+      ig = sp[0]; fg = sp[LH]; gg = sp[2 * LH]; og = sp[3 * LH]; c = sp[4 * LH];
+      if (s > 0) cprev = save[(((long)tp * B + row) * 2 + dir) * 5 * LH + 4 * LH + j];
+    }
+    if (s + 1 < T) {
+      if (!lstm_wait(flags, jb, (unsigned)(T - 1 - s), sync)) bad = true;
+      const float* A = dgates + ((long)tn * B + arow) * (8 * LH) + dir * 4 * LH + kbase;
+      float4 af[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) af[e] = aon ? *reinterpret_cast<const float4*>(A + 16 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e].x, bf[e].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e].y, bf[e].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e].z, bf[e].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e].w, bf[e].w, acc, 0, 0, 0);
+      }
+      if (i < 8) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][4 * q + r][i] = acc[r];
+      }
+      __syncthreads();
+      if (gate) {
+#pragma unroll
+        for (int v = 0; v < 8; v += 2) dh += red[v][wl][jj] + red[v + 1][wl][jj];
+      }
+    }
+    if (gate) {
+      const float tc = tanhf_(c);
+      const float dc = carry + dh * og * (1.f - tc * tc);
+      float* o = dgates + ((long)t * B + row) * (8 * LH) + dir * 4 * LH + j;
+      const float nanv = bad ? __builtin_nanf("") : 0.f;
+      o[0] = dc * gg * ig * (1.f - ig) + nanv;
+      o[LH] = dc * cprev * fg * (1.f - fg);
+      o[2 * LH] = dc * ig * (1.f - gg * gg);
+      o[3 * LH] = dh * tc * og * (1.f - og);
+      carry = dc * fg;
+    }
+    lstm_publish(flags, jb, (unsigned)(T - s));
+  }
+}
+
 // out[c][r] = in[r][c]
 __global__ void transpose_k(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
   __shared__ float t[32][33];
@@ -503,6 +723,49 @@ int tatt_lstm256_step_bwd(const float* save, const float* whhT, const float* dou
   TATT_CHECK_ARG(save && whhT && dout && dgates && dc_carry && s >= 0 && s < T && B > 0, "tatt_lstm256_step_bwd: bad arguments");
   hipLaunchKernelGGL(lstm_step_bwd_k, dim3(LH / 16, cdiv(B, 32), 2), dim3(256), 0, st, save, whhT, dout, dgates, dc_carry, s, T, B);
   TATT_LAUNCH_CHECK("lstm_step_bwd");
+  return TATT_OK;
+}
+
+static int lstm_num_xcd() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || n < 1 || n > 8) n = 8;
+  return n;
+}
+size_t tatt_rpe_chain_supported(void);   // gru.hip: same device requirements (gfx942 / gfx950, every XCD can hold its chains)
+
+size_t tatt_lstm256_chain_sync_words(void) { return (size_t)LSTM_SYNC_WORDS; }
+
+// All T steps of tatt_lstm256_step_fwd in one launch (h_0 = c_0 = 0).  sync: tatt_lstm256_chain_sync_words() uint32 that the caller
+// zeroes ONCE; sync[1] != 0 afterwards = a wait gave up (sticky across calls; results invalid, outputs NaN from that step on).
+int tatt_lstm256_chain_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* out,
+                           float* save, int T, int B, uint32_t* sync, hipStream_t st) {
+  TATT_CHECK_ARG(gi && whh_f && whh_b && bhh_f && bhh_b && out && sync && T > 0 && B > 0, "tatt_lstm256_chain_fwd: bad arguments");
+  TATT_CHECK_ARG(B <= 8 * LSTM_MAX_CHAINS, "tatt_lstm256_chain_fwd: at most %d rows (got %d): use the per-step launches", 8 * LSTM_MAX_CHAINS, B);
+  TATT_CHECK_ARG(tatt_rpe_chain_supported(), "tatt_lstm256_chain_fwd: this device cannot hold the chains (tatt_rpe_chain_supported() == 0): use the per-step launches");
+  TATT_CHECK_ARG(((((uintptr_t)gi) | ((uintptr_t)whh_f) | ((uintptr_t)whh_b) | ((uintptr_t)out)) & 15) == 0, "tatt_lstm256_chain_fwd: 16-byte aligned pointers required");
+  const int nxcd = lstm_num_xcd();
+  if (hipMemsetAsync(sync + 8, 0, (LSTM_SYNC_WORDS - 8) * 4, st) != hipSuccess) {
+    tatt_set_error("tatt_lstm256_chain_fwd: hipMemsetAsync failed");
+    return TATT_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(lstm_chain_fwd_k, dim3(512), dim3(256), 0, st, gi, whh_f, whh_b, bhh_f, bhh_b, out, save, T, B, sync, nxcd);
+  TATT_LAUNCH_CHECK("lstm_chain_fwd");
+  return TATT_OK;
+}
+
+// All T BPTT steps of tatt_lstm256_step_bwd (s = T-1 .. 0) in one launch; no dc_carry buffer (it lives in registers).  A sync buffer of its own.
+int tatt_lstm256_chain_bwd(const float* save, const float* whhT, const float* dout, float* dgates, int T, int B, uint32_t* sync, hipStream_t st) {
+  TATT_CHECK_ARG(save && whhT && dout && dgates && sync && T > 0 && B > 0, "tatt_lstm256_chain_bwd: bad arguments");
+  TATT_CHECK_ARG(B <= 8 * LSTM_MAX_CHAINS, "tatt_lstm256_chain_bwd: at most %d rows (got %d): use the per-step launches", 8 * LSTM_MAX_CHAINS, B);
+  TATT_CHECK_ARG(tatt_rpe_chain_supported(), "tatt_lstm256_chain_bwd: this device cannot hold the chains (tatt_rpe_chain_supported() == 0): use the per-step launches");
+  TATT_CHECK_ARG(((((uintptr_t)whhT) | ((uintptr_t)dgates)) & 15) == 0, "tatt_lstm256_chain_bwd: 16-byte aligned pointers required");
+  const int nxcd = lstm_num_xcd();
+  if (hipMemsetAsync(sync + 8, 0, (LSTM_SYNC_WORDS - 8) * 4, st) != hipSuccess) {
+    tatt_set_error("tatt_lstm256_chain_bwd: hipMemsetAsync failed");
+    return TATT_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(lstm_chain_bwd_k, dim3(512), dim3(512), 0, st, save, whhT, dout, dgates, T, B, sync, nxcd);
+  TATT_LAUNCH_CHECK("lstm_chain_bwd");
   return TATT_OK;
 }
 

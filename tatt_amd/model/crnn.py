@@ -12,6 +12,8 @@ reference's names, shapes and default initialisation; their `forward` is never c
 and pure data movement (slicing, transposed copies); every arithmetic step is a kernel of libtatt_hip.so — the trunk on
 the SR path's conv / BatchNorm / GEMM kernels, the rest in csrc/crnn.hip.  There is no CPU fallback.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -42,6 +44,30 @@ class _Plan:
     def __init__(self, mod):
         self.m, self.L = mod, lib()
         self.ws = None
+        # the T steps of each nn.LSTM as one launch of persistent workgroups (tatt_lstm256_chain_fwd / _bwd) where the device can hold
+        # the chains; TATT_LSTM_CHAIN=0 (A/B runs), other devices and B > 128: one launch per step
+        self.lstm_chain = os.environ.get("TATT_LSTM_CHAIN", "1") != "0"
+        self._sync_f = self._sync_b = None
+
+    def _chain(self, B):
+        return self.lstm_chain and B <= 128 and bool(self.L.rpe_chain_supported())
+
+    def _sync(self, which):
+        """The chain launches' flag buffer (zeroed once: word 1 is a sticky error flag), one per direction of the pass; the two
+        LSTM layers run one after the other on one stream and share it."""
+        t = getattr(self, which)
+        if t is None or t.device != self.dev:
+            t = torch.zeros(self.L.lstm256_chain_sync_words(), device=self.dev, dtype=torch.int32)
+            setattr(self, which, t)
+        return t
+
+    def check_lstm_chain(self):
+        """Raise if a chain launch of this plan ever reported a timed-out wait (synchronises; call at check points)."""
+        for which in ("_sync_f", "_sync_b"):
+            t = getattr(self, which)
+            if t is not None and int(t[1].item()) != 0:
+                raise RuntimeError(f"LSTM chain kernel ({which}) gave up waiting for its predecessor step: results are invalid; "
+                                   "set TATT_LSTM_CHAIN=0 to run the recurrence as one launch per step")
 
     def new(self, *shape):
         return torch.empty(shape, device=self.dev, dtype=torch.float32)
@@ -98,10 +124,14 @@ class _Plan:
         for d, sfx in enumerate(["", "_reverse"]):
             L.gemm(x, P[r + "weight_ih_l0" + sfx], gi[:, d * 1024:], P[r + "bias_ih_l0" + sfx], T * B, 1024, I, I, 1, I, 1, 2048, 1, 0, 0, 0,
                    0, self.pf, 1, None)
-        h = torch.zeros(2, 2, B, 256, device=self.dev)               # ping-pong [buf][dir][B][256]
-        c = torch.zeros(2, 2, B, 256, device=self.dev)
         rec = self.new(T * B, 512)
         sv = self.new(T * B, 2, 5, 256) if save else None
+        if self._chain(B):
+            L.lstm256_chain_fwd(gi, P[r + "weight_hh_l0"], P[r + "weight_hh_l0_reverse"], P[r + "bias_hh_l0"], P[r + "bias_hh_l0_reverse"],
+                                rec, sv, T, B, self._sync("_sync_f"))
+            return rec, sv
+        h = torch.zeros(2, 2, B, 256, device=self.dev)               # ping-pong [buf][dir][B][256]
+        c = torch.zeros(2, 2, B, 256, device=self.dev)
         for s in range(T):
             a, b = s & 1, (s + 1) & 1
             L.lstm256_step_fwd(gi, P[r + "weight_hh_l0"], P[r + "weight_hh_l0_reverse"], P[r + "bias_hh_l0"],
@@ -196,9 +226,12 @@ class _Plan:
         for d, sfx in enumerate(["", "_reverse"]):
             L.transpose(P[r + "weight_hh_l0" + sfx], whhT[d], 1024, 256)
         dgates = self.new(T * B, 2048)
-        dcc = torch.zeros(2, B, 256, device=self.dev)
-        for s in reversed(range(T)):
-            L.lstm256_step_bwd(sv, whhT, drec, dgates, dcc, s, T, B)
+        if self._chain(B):
+            L.lstm256_chain_bwd(sv, whhT, drec, dgates, T, B, self._sync("_sync_b"))
+        else:
+            dcc = torch.zeros(2, B, 256, device=self.dev)
+            for s in reversed(range(T)):
+                L.lstm256_step_bwd(sv, whhT, drec, dgates, dcc, s, T, B)
         dX = self.new(T * B, I)
         for d, sfx in enumerate(["", "_reverse"]):
             g = dgates[:, d * 1024:]

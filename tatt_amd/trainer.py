@@ -222,10 +222,14 @@ class SRTrainer:
         self.L.clip_adam(self.flat_p, self.flat_g, self.m, self.v, self.n, self.lr, self.betas[0], self.betas[1], self.eps,
                          self.max_norm, self.state, self.ws)
 
-    def verify_replicas(self):
-        """Raise unless every rank holds bit-identical parameters and optimiser moments (and the RPE chain kernels of the last step
-        completed without a timed-out wait); returns the rank count RCCL reports through a collective (1 without a process group)."""
+    def check_chains(self):
+        """Raise if a single-launch recurrence (RPE chains; LSTM chains in TATTTrainer) ever reported a timed-out wait.  Synchronises."""
         self.eng.check_rpe_chain()
+
+    def verify_replicas(self):
+        """Raise unless every rank holds bit-identical parameters and optimiser moments (and the chain kernels
+        completed without a timed-out wait); returns the rank count RCCL reports through a collective (1 without a process group)."""
+        self.check_chains()
         if not self.dp:
             return 1
         n = assert_replicas_identical(self.flat_p, "SR parameters")
@@ -479,6 +483,11 @@ class TATTTrainer(SRTrainer):
 
     def extra_grad_buffers(self):
         return [self.s_g]
+
+    def check_chains(self):
+        super().check_chains()
+        self.teacher.plan().check_lstm_chain()
+        self.student.plan().check_lstm_chain()
 
     def verify_replicas(self):
         n = super().verify_replicas()

@@ -134,3 +134,55 @@ def test_semantic_loss_module_vs_reference_golden():
     loss.backward()
     assert abs(loss.item() - float(g["sem_loss"])) < 1e-5 * abs(float(g["sem_loss"]))
     assert rel_l2(pred.grad.cpu().double().numpy(), g["sem_dpred"]) < 1e-4
+
+
+@pytest.mark.parametrize("B,T", [(64, 26), (5, 7), (33, 26), (128, 3)])
+def test_lstm256_chain_equals_step_launches_and_fp64(B, T):
+    """tatt_lstm256_chain_fwd / _bwd (all T steps in one launch of persistent workgroups; B = 64 is the BASELINE batch, the others
+    exercise ragged row blocks and one / several chains per XCD) against the per-step launches (same products, same summation order:
+    1e-6) and against nn.LSTM autograd in fp64; the sticky error flag must stay clear."""
+    from tatt_amd.lib import lib
+    L = lib()
+    if not L.rpe_chain_supported():
+        pytest.skip("device cannot hold the chains")
+    torch.manual_seed(3)
+    lstm = torch.nn.LSTM(64, 256, bidirectional=True).double()
+    x = torch.randn(T, B, 64, dtype=torch.float64)
+    out, _ = lstm(x)
+    dout = torch.randn(T, B, 512, dtype=torch.float64)
+    out.backward(dout)
+    cu = lambda t: t.detach().float().contiguous().cuda()
+    sfx = ["", "_reverse"]
+    W = {n: cu(p) for n, p in lstm.named_parameters()}
+    gi = torch.cat([x.reshape(T * B, 64) @ getattr(lstm, "weight_ih_l0" + d).detach().T + getattr(lstm, "bias_ih_l0" + d).detach() for d in sfx], 1)
+    gi = cu(gi)
+    wargs = (W["weight_hh_l0"], W["weight_hh_l0_reverse"], W["bias_hh_l0"], W["bias_hh_l0_reverse"])
+    # per-step launches
+    h, c = torch.zeros(2, 2, B, 256, device="cuda"), torch.zeros(2, 2, B, 256, device="cuda")
+    rec0, sv0 = torch.empty(T * B, 512, device="cuda"), torch.empty(T * B, 2, 5, 256, device="cuda")
+    for s in range(T):
+        a, b = s & 1, (s + 1) & 1
+        L.lstm256_step_fwd(gi, *wargs, h[a], c[a], h[b], c[b], rec0, sv0, s, T, B)
+    whhT = torch.stack([W["weight_hh_l0" + d].t().contiguous() for d in sfx])
+    do = cu(dout.reshape(T * B, 512))
+    dg0, dcc = torch.empty(T * B, 2048, device="cuda"), torch.zeros(2, B, 256, device="cuda")
+    for s in reversed(range(T)):
+        L.lstm256_step_bwd(sv0, whhT, do, dg0, dcc, s, T, B)
+    # chains (twice: the flag buffer is reused, its working part cleared by the call)
+    sync_f = torch.zeros(L.lstm256_chain_sync_words(), device="cuda", dtype=torch.int32)
+    sync_b = torch.zeros(L.lstm256_chain_sync_words(), device="cuda", dtype=torch.int32)
+    for _ in range(2):
+        rec1, sv1 = torch.full((T * B, 512), float("nan"), device="cuda"), torch.empty(T * B, 2, 5, 256, device="cuda")
+        L.lstm256_chain_fwd(gi, *wargs, rec1, sv1, T, B, sync_f)
+        dg1 = torch.full((T * B, 2048), float("nan"), device="cuda")
+        L.lstm256_chain_bwd(sv1, whhT, do, dg1, T, B, sync_b)
+        torch.cuda.synchronize()
+        assert int(sync_f[1]) == 0 and int(sync_b[1]) == 0
+        for got, ref, what in ((rec1, rec0, "out"), (sv1, sv0, "saved gates"), (dg1, dg0, "gate gradients")):
+            assert torch.isfinite(got).all(), what
+            assert rel_l2(got.cpu().numpy(), ref.cpu().numpy()) < 1e-6, what      # same products; the compiler contracts the gate math differently
+    assert rel_l2(rec1.view(T, B, 512).cpu().numpy(), out.detach().numpy()) < 2e-5
+    # gate gradients -> dW_ih = dgates^T x against autograd
+    for d, n in enumerate(sfx):
+        dW = dg1[:, d * 1024:(d + 1) * 1024].double().cpu().t() @ x.reshape(T * B, 64)
+        assert rel_l2(dW.numpy(), getattr(lstm, "weight_ih_l0" + n).grad.numpy()) < 5e-5
