@@ -30,7 +30,7 @@ RPE_INPUT_PROJ_FLOP = 3 * 0.403e9    # per image as the reference executes it: W
                                      # the input is the same at every step, so this build computes it once per batch (hoisted)
 RPE_SERIAL_FLOP = 3 * 0.201e9        # per image: h W_hh^T of the RPE recurrence; the second pass of a TSC step reuses the first one's chain
 PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 matrix peak
-CONV_TRAFFIC_BYTES = 34.9e6          # profiles/r02_conv_traffic.md
+CONV_TRAFFIC_BYTES = 34.9e6          # profiles/r03_traffic.md (fp32 MFMA and bf16 legs; f32x3: 35.0e6)
 
 
 def conv_roofline(L, B, iters=10, bf16=False, x3=False):
@@ -85,20 +85,23 @@ def conv_roofline(L, B, iters=10, bf16=False, x3=False):
         # price it against HBM with the algorithmic bytes of an SRB-shaped launch scaled to the mix (in + out + weights, fp32).
         byts = sum(4.0 * (c[4] * c[5] * c[6] * (c[7] + c[8]) + 9 * c[7] * c[8]) for _, c in calls) / len(calls)
         return {"bound": "hbm", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST,BF16> (3x3 conv fwd+dgrad, per-step mix of %d launches)" % len(calls),
-                "achieved": round(byts / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byts / dt / 8e12, 4), "traffic": None,
+                "achieved": round(byts / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byts / dt / 8e12, 4), "traffic": CONV_TRAFFIC_BYTES,
+                "traffic_note": "bytes per SRB-shaped launch of gemm_halo_kernel (algorithmic 33.7e6): rocprofv3 --pmc 2*FETCH_SIZE + WRITE_SIZE, "
+                                "separate passes, profiles/r03_traffic.md (not re-measured by this run)",
                 "launch_us": round(dt * 1e6, 2), "bytes_per_launch": byts, "tflops": round(ach, 2), "launches_per_step": len(calls)}
     if x3:
         # three-piece split: six bf16 MFMA terms per fp32 product -- executed matrix FLOPs = 6 x algorithmic, priced against the dense bf16 peak
         return {"bound": "mfma", "kernel": "gemm_x3_kernel<OP_IM2COL,OP_CONVW_P,TAP9,EPI 0|1|2> (3x3 conv fwd+dgrad, fp32 products from three bf16 pieces "
                 "per operand, per-step mix of %d launches)" % len(calls), "achieved": round(6 * ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(6 * ach / 2500.0, 4), "traffic": None, "launch_us": round(dt * 1e6, 2), "flop_per_launch": fl,
+                "frac": round(6 * ach / 2500.0, 4), "traffic": 35.0e6,
+                "traffic_note": "bytes per SRB-shaped launch of gemm_halo_kernel<X3> (algorithmic 33.7e6), profiles/r03_traffic.md", "launch_us": round(dt * 1e6, 2), "flop_per_launch": fl,
                 "algorithmic_tflops": round(ach, 2), "algorithmic_frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                 "launches_per_step": len(calls)}
     return {"bound": "mfma", "kernel": "gemm_kernel<OP_IM2COL,OP_CONVW_P,FAST,TAP9,EPI 0|1|2> (3x3 conv fwd+dgrad with the step's epilogue variants, per-step mix of %d launches)" % len(calls),
             "measured": "standalone replay of the step's launch mix on an otherwise idle GPU, HIP events on the launch stream",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": CONV_TRAFFIC_BYTES, "traffic_note": "bytes per SRB-shaped launch (algorithmic 33.7e6): rocprofv3 --pmc 2*FETCH_SIZE"
-            " + WRITE_SIZE, separate passes, profiles/r02_conv_traffic.md (not re-measured by this run)",
+            " + WRITE_SIZE, separate passes, profiles/r03_traffic.md (not re-measured by this run)",
             "launch_us": round(dt * 1e6, 2), "flop_per_launch": fl, "launches_per_step": len(calls)}
 
 
