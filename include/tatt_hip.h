@@ -191,7 +191,9 @@ int tatt_attn_kv_final(const float* part, int nchunk, int B, float* dK, float* d
  *       linear2.bias, norm2.weight, norm2.bias, norm3.weight, norm3.bias); saved = host array [2][7] of [B*Lq][64] outputs the
  *       backward pass reads (qin, Q, context, LayerNorm2 input, LayerNorm2 output, dropped FFN hidden, LayerNorm3 input);
  *       seed_sites = host array [2][4] of tatt_seed_site words (attention, dropout2, FFN dropout, dropout3); thresh / scale /
- *       seed_dev as for tatt_ln_fwd.  Lq % 128 == 0.
+ *       seed_dev as for tatt_ln_fwd.  Lq % 128 == 0.  npass = 2: the B batch elements are two passes of B/2 over the same weights (the
+ *       TSC step's second SR forward, interfaces/super_resolution_eng.py:254-261, batched with the first): query_pos has B/2 * Lq rows
+ *       and serves both, dropout indices count within a pass, seed_sites = [2 passes][2 layers][4] (tatt_dec_bwd: [2 passes][4]).
  *   tatt_dec_bwd: one layer (1 first, then 0).  dt3_in: gradient wrt the layer's output from the layer above (NULL for layer 1);
  *       dtp: gradient of tp_map; dtgt / dqp (+)= the gradients wrt the layer's input and query_pos; dY = host array [4] of [B*Lq][64]
  *       outputs (dQ, d attn-out, d hidden, d ffn-out), the left operands of the four weight gradients dY^T X with X = saved qin,
@@ -205,8 +207,8 @@ size_t tatt_dec_bwd_kvpart_floats(int B, int Lq);
 size_t tatt_dec_bwd_lnpart_floats(int B, int Lq);
 int tatt_dec_pack_w(const float* const* W, float* packed, hipStream_t stream);
 int tatt_dec_pack_kv(const float* Kp, const float* Vp, float* table, int B, hipStream_t stream);
-int tatt_dec_fwd(const float* tgt, const float* qp, const float* packed_w, const float* const* kv, const float* const* params, const float* norm_w, const float* norm_b, float* const* saved, float* tp_map, int B, int Lq, const uint32_t* seed_sites, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t stream);
-int tatt_dec_bwd(int layer, const float* dt3_in, const float* dtp, const float* packed_w, const float* kv, const float* const* params, const float* norm_w, float* const* saved, float* dtgt, int dtgt_accumulate, float* dqp, int dqp_accumulate, float* const* dY, float* kvpart, float* lnpart, int B, int Lq, const uint32_t* seed_sites, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t stream);
+int tatt_dec_fwd(const float* tgt, const float* qp, const float* packed_w, const float* const* kv, const float* const* params, const float* norm_w, const float* norm_b, float* const* saved, float* tp_map, int B, int Lq, int npass, const uint32_t* seed_sites, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t stream);
+int tatt_dec_bwd(int layer, const float* dt3_in, const float* dtp, const float* packed_w, const float* kv, const float* const* params, const float* norm_w, float* const* saved, float* dtgt, int dtgt_accumulate, float* dqp, int dqp_accumulate, float* const* dY, float* kvpart, float* lnpart, int B, int Lq, int npass, const uint32_t* seed_sites, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t stream);
 int tatt_dec_ln_final(const float* lnpart, int B, int Lq, float* const* grads, hipStream_t stream);
 
 /* ---- element-wise / layout (model/tsrn.py:599 PReLU, :1042-1043 PixelShuffle+mish, :683 sigmoid, :208, :212;

@@ -34,7 +34,7 @@ struct DecLayer {
   const float4* kv;                            // [B][48][64] float4
   const float* p[8];                           // bq, bo, b1, b2, norm2.weight, norm2.bias, norm3.weight, norm3.bias
   float* sv[NSAVE];
-  uint32_t site[4];                            // tatt_seed_site words: attention, dropout2, FFN dropout, dropout3
+  uint32_t site[2][4];                         // per pass: tatt_seed_site words of attention, dropout2, FFN dropout, dropout3
 };
 
 struct DecFwdArgs {
@@ -45,6 +45,7 @@ struct DecFwdArgs {
   const float* nb;
   float* tp_map;
   int Lq;
+  uint32_t pass_rows;                          // rows of one pass (B * Lq): rows >= pass_rows are the second pass of a two-pass (TSC) batch
   uint32_t thresh;
   float scale;
   const uint32_t* seed_dev;
@@ -180,19 +181,21 @@ __device__ __forceinline__ void head_probs(f32x16& p, const T32& Q, const float4
 // ================================================================================================================================
 __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
   const int lane = threadIdx.x & 63, hi = lane >> 5, wv = threadIdx.x >> 6;
-  const uint32_t row = (uint32_t)(blockIdx.x * 128 + wv * 32 + (lane & 31));
-  const int b = (int)(row / (uint32_t)A.Lq), q = (int)(row - (uint32_t)b * (uint32_t)A.Lq);
-  const long ro = (long)row * E;
+  const uint32_t grow = (uint32_t)(blockIdx.x * 128 + wv * 32 + (lane & 31));   // row of the batch: addresses, key / value table
+  const int ps = grow >= A.pass_rows;                                           // pass (workgroup-uniform: pass_rows % 128 == 0)
+  const uint32_t row = grow - (ps ? A.pass_rows : 0u);                          // row within its pass: dropout indices, query_pos
+  const int b = (int)(row / (uint32_t)A.Lq), q = (int)(row - (uint32_t)b * (uint32_t)A.Lq), gb = (int)(grow / (uint32_t)A.Lq);
+  const long ro = (long)grow * E, rq = (long)row * E;
   const uint32_t sd = A.seed_dev ? A.seed_dev[0] * 0x85EBCA77u : 0u;
   T32 tgt, tp;
   t_load(tgt, A.tgt + ro, hi);
 #pragma unroll
   for (int li = 0; li < 2; ++li) {
     const DecLayer& L = A.L[li];
-    const float4* __restrict__ kvb = L.kv + (long)b * KV_SLOTS * 64;
+    const float4* __restrict__ kvb = L.kv + (long)gb * KV_SLOTS * 64;
     T32 x, y;
     // ---- qin = tgt + query_pos ; Q = Wq qin + bq
-    t_load(x, A.qp + ro, hi);
+    t_load(x, A.qp + rq, hi);
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
       f32x16 p;
       head_probs(p, y, kvb, h, lane, hi);
       if (A.thresh) {
-        const uint32_t ib = (uint32_t)((((long)b * NH + h) * A.Lq + q) * S), ss = L.site[0] + sd;
+        const uint32_t ib = (uint32_t)((((long)b * NH + h) * A.Lq + q) * S), ss = L.site[ps][0] + sd;
 #pragma unroll
         for (int i = 0; i < 14; ++i) p[i] *= dmask(ss, ib + (uint32_t)key_of(i, hi), A.thresh, A.scale);
       }
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
     t_load(y, L.p[1], hi);
     mm64(y, L.Wf + 1 * 1024, lane, x);
     if (A.thresh) {
-      const uint32_t ss = L.site[1] + sd;
+      const uint32_t ss = L.site[ps][1] + sd;
 #pragma unroll
       for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) x.b[ob][i] = fmaxf(x.b[ob][i], 0.f);
     if (A.thresh) {
-      const uint32_t ss = L.site[2] + sd;
+      const uint32_t ss = L.site[ps][2] + sd;
 #pragma unroll
       for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
     t_load(y, L.p[3], hi);
     mm64(y, L.Wf + 3 * 1024, lane, x);
     if (A.thresh) {
-      const uint32_t ss = L.site[3] + sd;
+      const uint32_t ss = L.site[ps][3] + sd;
 #pragma unroll
       for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -304,7 +307,8 @@ struct DecBwdArgs {
   float* dY[4];            // dQ, da, dh, df
   float* kvpart;           // [Lq/128][2][B*26][64]: one partial per workgroup (128 tokens)
   float* lnpart;           // [R0/128][6][64]: d norm2.weight, d norm2.bias, d norm3.weight, d norm3.bias, d decoder.norm.weight, .bias
-  int Lq, B;
+  int Lq, B;               // B: batch elements of the whole launch (both passes)
+  uint32_t pass_rows;
   uint32_t thresh;
   float scale;
   const uint32_t* seed_dev;
@@ -413,12 +417,14 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs A) {
   __shared__ __attribute__((aligned(16))) float tiles[4][3][32 * TS];   // 13,824 floats; reused at the end for the 4 x 3,328 dK / dV partials
   __shared__ float lnred[4][6 * 64];
   const int lane = threadIdx.x & 63, hi = lane >> 5, wv = threadIdx.x >> 6;
-  const uint32_t row = (uint32_t)(blockIdx.x * 128 + wv * 32 + (lane & 31));
-  const int b = (int)(row / (uint32_t)A.Lq), q = (int)(row - (uint32_t)b * (uint32_t)A.Lq);
-  const long ro = (long)row * E;
+  const uint32_t grow = (uint32_t)(blockIdx.x * 128 + wv * 32 + (lane & 31));
+  const int ps = grow >= A.pass_rows;
+  const uint32_t row = grow - (ps ? A.pass_rows : 0u);     // row within its pass (dropout indices)
+  const int b = (int)(row / (uint32_t)A.Lq), q = (int)(row - (uint32_t)b * (uint32_t)A.Lq), gb = (int)(grow / (uint32_t)A.Lq);
+  const long ro = (long)grow * E;
   const uint32_t sd = A.seed_dev ? A.seed_dev[0] * 0x85EBCA77u : 0u;
   const DecLayer& L = A.L;
-  const float4* __restrict__ kvb = L.kv + (long)b * KV_SLOTS * 64;
+  const float4* __restrict__ kvb = L.kv + (long)gb * KV_SLOTS * 64;
   float* lnp = lnred[wv];
   float* tA = tiles[wv][0];
   float* tB1 = tiles[wv][1];
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs A) {
   // ---- FFN backward
   g = dt2;
   if (A.thresh) {
-    const uint32_t ss = L.site[3] + sd;
+    const uint32_t ss = L.site[ps][3] + sd;
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs A) {
   ln_bwd_t(dtgt, xh, dt2, rstd, L.p[4], lnp, lane, hi);            // dtgt = dv2 (residual branch)
   g = dtgt;
   if (A.thresh) {
-    const uint32_t ss = L.site[1] + sd;
+    const uint32_t ss = L.site[ps][1] + sd;
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs A) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) m[i] = i < 14 ? 1.f : 0.f;
     if (A.thresh) {
-      const uint32_t ib = (uint32_t)((((long)b * NH + h) * A.Lq + q) * S), ss = L.site[0] + sd;
+      const uint32_t ib = (uint32_t)((((long)b * NH + h) * A.Lq + q) * S), ss = L.site[ps][0] + sd;
 #pragma unroll
       for (int i = 0; i < 14; ++i) m[i] = dmask(ss, ib + (uint32_t)key_of(i, hi), A.thresh, A.scale);
     }
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs A) {
     const float* red = &tiles[0][0][0];
     const int chunk = q >> 7;                                      // workgroup-uniform: its 128 tokens share b and q / 128
     const long n = (long)A.B * S * E;
-    float* pv = A.kvpart + ((long)chunk * 2) * n + (long)b * S * E;
+    float* pv = A.kvpart + ((long)chunk * 2) * n + (long)gb * S * E;
     for (int idx = threadIdx.x; idx < 2 * S * E; idx += 256) {
       const float v = (red[idx] + red[2 * S * E + idx]) + (red[4 * S * E + idx] + red[6 * S * E + idx]);
       const int which = idx >= S * E;
@@ -726,7 +732,7 @@ int tatt_dec_pack_kv(const float* Kp, const float* Vp, float* table, int B, hipS
 }
 
 static int fill_layer(DecLayer& L, const float* packed_w, int li, const float* kv, const float* const* params, float* const* saved,
-                      const uint32_t* sites, const char* who) {
+                      const uint32_t* sites, const uint32_t* sites2, const char* who) {
   L.Wf = reinterpret_cast<const float4*>(packed_w) + (long)li * 8 * 1024;
   L.kv = reinterpret_cast<const float4*>(kv);
   TATT_CHECK_ARG(kv && (((uintptr_t)kv) & 15) == 0, "%s: layer %d key/value table missing or unaligned", who, li);
@@ -738,23 +744,29 @@ static int fill_layer(DecLayer& L, const float* packed_w, int li, const float* k
     TATT_CHECK_ARG(saved[i] && (((uintptr_t)saved[i]) & 15) == 0, "%s: layer %d saved tensor %d missing or not 16-byte aligned", who, li, i);
     L.sv[i] = saved[i];
   }
-  for (int i = 0; i < 4; ++i) L.site[i] = sites[i];
+  for (int i = 0; i < 4; ++i) {
+    L.site[0][i] = sites[i];
+    L.site[1][i] = sites2 ? sites2[i] : sites[i];
+  }
   return TATT_OK;
 }
 
 int tatt_dec_fwd(const float* tgt, const float* qp, const float* packed_w, const float* const* kv, const float* const* params,
-                 const float* norm_w, const float* norm_b, float* const* saved, float* tp_map, int B, int Lq, const uint32_t* seed_sites,
-                 uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t st) {
+                 const float* norm_w, const float* norm_b, float* const* saved, float* tp_map, int B, int Lq, int npass,
+                 const uint32_t* seed_sites, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t st) {
   TATT_CHECK_ARG(tgt && qp && packed_w && kv && params && norm_w && norm_b && saved && tp_map && seed_sites, "tatt_dec_fwd: NULL argument");
   TATT_CHECK_ARG(B > 0 && Lq > 0 && Lq % 128 == 0 && (long)B * Lq * E < (1L << 32), "tatt_dec_fwd: Lq must be a multiple of 128 and B*Lq*64 < 2^32");
+  TATT_CHECK_ARG((npass == 1 || npass == 2) && B % npass == 0, "tatt_dec_fwd: npass must be 1 or 2 and divide B");
   TATT_CHECK_ARG(((((uintptr_t)tgt) | ((uintptr_t)qp) | ((uintptr_t)tp_map) | ((uintptr_t)packed_w) | ((uintptr_t)norm_w) | ((uintptr_t)norm_b)) & 15) == 0,
                  "tatt_dec_fwd: pointers must be 16-byte aligned");
   DecFwdArgs a;
   for (int li = 0; li < 2; ++li) {
-    int rc = fill_layer(a.L[li], packed_w, li, kv[li], params + li * 8, saved + li * NSAVE, seed_sites + li * 4, "tatt_dec_fwd");
+    int rc = fill_layer(a.L[li], packed_w, li, kv[li], params + li * 8, saved + li * NSAVE, seed_sites + li * 4,
+                        npass == 2 ? seed_sites + 8 + li * 4 : nullptr, "tatt_dec_fwd");
     if (rc) return rc;
   }
   a.tgt = tgt; a.qp = qp; a.nw = norm_w; a.nb = norm_b; a.tp_map = tp_map; a.Lq = Lq;
+  a.pass_rows = (uint32_t)((long)(B / npass) * Lq);
   a.thresh = thresh; a.scale = scale; a.seed_dev = seed_dev;
   hipLaunchKernelGGL(dec_fwd_kernel, dim3((unsigned)((long)B * Lq / 128)), dim3(256), 0, st, a);
   TATT_LAUNCH_CHECK("dec_fwd");
@@ -763,22 +775,23 @@ int tatt_dec_fwd(const float* tgt, const float* qp, const float* packed_w, const
 
 int tatt_dec_bwd(int layer, const float* dt3_in, const float* dtp, const float* packed_w, const float* kv, const float* const* params,
                  const float* norm_w, float* const* saved, float* dtgt, int dtgt_accumulate, float* dqp, int dqp_accumulate,
-                 float* const* dY, float* kvpart, float* lnpart, int B, int Lq, const uint32_t* seed_sites, uint32_t thresh, float scale,
-                 const uint32_t* seed_dev, hipStream_t st) {
+                 float* const* dY, float* kvpart, float* lnpart, int B, int Lq, int npass, const uint32_t* seed_sites, uint32_t thresh,
+                 float scale, const uint32_t* seed_dev, hipStream_t st) {
   TATT_CHECK_ARG((layer == 0 || layer == 1) && dtp && packed_w && params && norm_w && saved && dtgt && dqp && dY && kvpart && lnpart && seed_sites,
                  "tatt_dec_bwd: bad arguments");
   TATT_CHECK_ARG(B > 0 && Lq > 0 && Lq % 128 == 0 && (long)B * Lq * E < (1L << 32), "tatt_dec_bwd: Lq must be a multiple of 128 and B*Lq*64 < 2^32");
+  TATT_CHECK_ARG((npass == 1 || npass == 2) && B % npass == 0, "tatt_dec_bwd: npass must be 1 or 2 and divide B");
   TATT_CHECK_ARG(((((uintptr_t)dt3_in) | ((uintptr_t)dtp) | ((uintptr_t)dtgt) | ((uintptr_t)dqp) | ((uintptr_t)norm_w)) & 15) == 0,
                  "tatt_dec_bwd: pointers must be 16-byte aligned");
   DecBwdArgs a;
-  int rc = fill_layer(a.L, packed_w, layer, kv, params, saved, seed_sites, "tatt_dec_bwd");
+  int rc = fill_layer(a.L, packed_w, layer, kv, params, saved, seed_sites, npass == 2 ? seed_sites + 4 : nullptr, "tatt_dec_bwd");
   if (rc) return rc;
   for (int i = 0; i < 4; ++i) {
     TATT_CHECK_ARG(dY[i] && (((uintptr_t)dY[i]) & 15) == 0, "tatt_dec_bwd: dY[%d] missing or not 16-byte aligned", i);
     a.dY[i] = dY[i];
   }
   a.dt3_in = dt3_in; a.dtp = dtp; a.nw = norm_w; a.dtgt = dtgt; a.dtgt_acc = dtgt_accumulate; a.dqp = dqp; a.dqp_acc = dqp_accumulate;
-  a.kvpart = kvpart; a.lnpart = lnpart; a.Lq = Lq; a.B = B; a.thresh = thresh; a.scale = scale; a.seed_dev = seed_dev;
+  a.kvpart = kvpart; a.lnpart = lnpart; a.Lq = Lq; a.B = B; a.pass_rows = (uint32_t)((long)(B / npass) * Lq); a.thresh = thresh; a.scale = scale; a.seed_dev = seed_dev;
   hipLaunchKernelGGL(dec_bwd_kernel, dim3((unsigned)((long)B * Lq / 128)), dim3(256), 0, st, a);
   TATT_LAUNCH_CHECK("dec_bwd");
   return TATT_OK;

@@ -375,39 +375,54 @@ class Engine:
 
     # ---- BatchNorm fused into the producing launch (tatt_conv_fwd_bn / tatt_gemm_cat_bnbwd): the row reductions of both passes run
     # in the epilogue of the convolution / GEMM that writes the tensor, one (mean, M2) or (sum g, sum g xhat) pair per 128-row tile
-    def conv_bn(self, pre_bn, x, W, b, B, H, Wd, Cin, Cout, k, train, act, res=None):
+    def conv_bn(self, pre_bn, x, W, b, B, H, Wd, Cin, Cout, k, train, act, res=None, ng=1):
         """y = act(BatchNorm(conv(x))) (+ res).  Training mode: batch statistics from the convolution's epilogue.
-        Returns (conv output, y, stat)."""
+        Returns (conv output, y, stat).  ng = 2: the B images are two passes of B/2 (the batched TSC step): ONE convolution launch,
+        BatchNorm statistics / running-statistic updates / apply per pass, in pass order; stat is then [2][2][Cout]."""
         P, R, T = self.P, B * H * Wd, k * k
         c = self.new(R, Cout)
         if not train:
+            if ng != 1:
+                raise RuntimeError("two-pass batches are a training-mode construct")
             self.conv(x, W, b, c, B, H, Wd, Cin, Cout, k)
             y, stat = self.bn(pre_bn, c, R, Cout, False, act, res=res)
             return c, y, stat
-        nblk = -(-R // 128)
-        part = self.new(nblk * 2 * Cout)
+        Rg = R // ng
+        if Rg % 128:
+            raise RuntimeError("conv_bn: rows per pass must be a multiple of 128")
+        nblk = Rg // 128
+        part = self.new(ng * nblk * 2 * Cout)
         self.L.conv_fwd_bn(x, self._packed(W, Cout, Cin, k)[0], b, c, B, H, Wd, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, self.pf, 1,
                            None, 0, None, None, None, 0, part)
-        stat = self.new(2, Cout)
-        self.L.bn_stats_from_partial(part, nblk, 128, R, Cout, 1e-5, 0.1, stat, P[pre_bn + "running_mean"], P[pre_bn + "running_var"])
-        self._nbt.append(P[pre_bn + "num_batches_tracked"])
+        stat = self.new(ng, 2, Cout)
         y = self.new(R, Cout)
-        self.L.bn_apply(c, Cout, stat, P[pre_bn + "weight"], P[pre_bn + "bias"], res, Cout, y, Cout, R, Cout, act)
-        return c, y, stat
+        for g in range(ng):
+            self.L.bn_stats_from_partial(part[g * nblk * 2 * Cout:], nblk, 128, Rg, Cout, 1e-5, 0.1, stat[g], P[pre_bn + "running_mean"],
+                                         P[pre_bn + "running_var"])
+            self._nbt.append(P[pre_bn + "num_batches_tracked"])
+            self.L.bn_apply(c[g * Rg:], Cout, stat[g], P[pre_bn + "weight"], P[pre_bn + "bias"], None if res is None else res[g * Rg:], Cout,
+                            y[g * Rg:], Cout, Rg, Cout, act)
+        return c, y, (stat[0] if ng == 1 else stat)
 
-    def conv_dgrad_bn(self, dy, W, B, H, Wd, Cin, Cout, k, pre_bn, bn_x, stat, act, train, G):
+    def conv_dgrad_bn(self, dy, W, B, H, Wd, Cin, Cout, k, pre_bn, bn_x, stat, act, train, G, ng=1):
         """dx through conv^T (forward weight W [Cout,Cin,k,k]) and the act(BatchNorm) in front of the convolution's input:
-        returns (g = conv^T(dy) * act'(bn(bn_x)) -- for act 0 the plain input gradient --, d bn_x)."""
+        returns (g = conv^T(dy) * act'(bn(bn_x)) -- for act 0 the plain input gradient --, d bn_x).  ng = 2: one launch per pass
+        (the epilogue reads ONE set of batch statistics)."""
         P, R, T = self.P, B * H * Wd, k * k
         g = self.new(R, Cin)
-        nblk = -(-R // 128)
-        part = self.new(nblk * 2 * Cin)
-        self.L.conv_fwd_bn(dy, self._packed(W, Cout, Cin, k)[1], None, g, B, H, Wd, Cout, Cin, k, k, Cout, Cin, T * Cout, 1, 0, Cout, self.pf, 2,
-                           bn_x, Cin, stat, P[pre_bn + "weight"], P[pre_bn + "bias"], act, part)
-        return g, self.bn_bwd_part(pre_bn, bn_x, g, stat, part, nblk, R, Cin, train, G)
+        Rg, Bg = R // ng, B // ng
+        nblk = -(-Rg // 128)
+        dx = self.new(R, Cin)
+        for q in range(ng):
+            part = self.new(nblk * 2 * Cin)
+            st = stat if ng == 1 else stat[q]
+            self.L.conv_fwd_bn(dy[q * Rg:], self._packed(W, Cout, Cin, k)[1], None, g[q * Rg:], Bg, H, Wd, Cout, Cin, k, k, Cout, Cin, T * Cout, 1, 0,
+                               Cout, self.pf, 2, bn_x[q * Rg:], Cin, st, P[pre_bn + "weight"], P[pre_bn + "bias"], act, part)
+            self.bn_bwd_part(pre_bn, bn_x[q * Rg:], g[q * Rg:], st, part, nblk, Rg, Cin, train, G, dx=dx[q * Rg:])
+        return g, dx
 
-    def bn_bwd_part(self, pre, x, g, stat, part, nblk, R, C, train, G):
-        dx = self.new(R, C)
+    def bn_bwd_part(self, pre, x, g, stat, part, nblk, R, C, train, G, dx=None):
+        dx = self.new(R, C) if dx is None else dx
         self.L.bn_bwd_from_partial(x, C, g, C, stat, self.P[pre + "weight"], self.P[pre + "bias"], part, nblk, dx, C, G[pre + "weight"],
                                    G[pre + "bias"], R, C, 1 if train else 0, 1, 0, self.new(2 * C))
         return dx
@@ -474,7 +489,7 @@ class Engine:
             ctx[key] = (out, sv)
         return out
 
-    def gru_block_bwd(self, pre, dout, inputs, B, H, W, vertical, ctx, key, G, bn=None):
+    def gru_block_bwd(self, pre, dout, inputs, B, H, W, vertical, ctx, key, G, bn=None, ng=1):
         """inputs: list of (x [R,64], dx [R,64], acc) per concatenated input.  Writes parameter grads, input grads into dx.
         bn = (pre_bn, bn_x, stat): the first input is the output of that (activation-free) BatchNorm; the GEMM's epilogue then
         also reduces (sum g, sum g xhat) over its rows and the partial sums are returned (part, nblk) for bn_bwd_part()."""
@@ -505,11 +520,16 @@ class Engine:
             return None
         pre_bn, bn_x, stat = bn
         assert inputs[0][2] == 0
-        nblk = -(-R // 128)
-        part = self.new(nblk * 2 * 64)
-        L.gemm_cat_bnbwd(dgi, None, 0, Wf, inputs[0][1], inputs[1][1] if two else None, 64, None, R, Cin, 192, 192, 1, Cin, 64, 64,
-                         0, inputs[1][2] if two else 0, self.pl, bn_x, 64, stat, P[pre_bn + "weight"], P[pre_bn + "bias"], 0, 64, part)
-        return part, nblk
+        Rg = R // ng                                          # ng = 2: one launch per pass (the epilogue reads one set of batch statistics)
+        nblk = -(-Rg // 128)
+        parts = []
+        for q in range(ng):
+            part = self.new(nblk * 2 * 64)
+            L.gemm_cat_bnbwd(dgi[q * Rg:], None, 0, Wf, inputs[0][1][q * Rg:], inputs[1][1][q * Rg:] if two else None, 64, None, Rg, Cin, 192, 192, 1,
+                             Cin, 64, 64, 0, inputs[1][2] if two else 0, self.pl, bn_x[q * Rg:], 64, stat if ng == 1 else stat[q],
+                             P[pre_bn + "weight"], P[pre_bn + "bias"], 0, 64, part)
+            parts.append(part)
+        return (parts[0] if ng == 1 else parts), nblk
 
     # ---- attention block pieces ------------------------------------------------------------------------------------
     def mha_fwd(self, pre, q_in, k_in, v_in, B, Lq, cfg):
@@ -574,32 +594,37 @@ class Engine:
         return [P[d + "multihead_attn.in_proj_bias"], P[d + "multihead_attn.out_proj.bias"], P[d + "linear1.bias"], P[d + "linear2.bias"],
                 P[d + "norm2.weight"], P[d + "norm2.bias"], P[d + "norm3.weight"], P[d + "norm3.bias"]]
 
-    def _dec_sites(self, li, cfg):
-        c = [cfg(f"dec{li}_{k}") for k in ("attn", "drop2", "ffn", "drop3")]
-        return [x[0] for x in c], c[0][1], c[0][2], c[0][3]
+    def _dec_sites(self, li, cfgs):
+        """cfgs: one dropout-config function per pass.  -> (site words [pass][4], thresh, scale, seed_dev)"""
+        c = [[cfg(f"dec{li}_{k}") for k in ("attn", "drop2", "ffn", "drop3")] for cfg in cfgs]
+        return [x[0] for cp in c for x in cp], c[0][0][1], c[0][0][2], c[0][0][3]
 
-    def _dec_call(self, fn, layer, tgt, qp, dec_w, dec_kv, saved, tp_map, B, Lq, cfg, extra=None):
+    def _dec_call(self, fn, layer, tgt, qp, dec_w, dec_kv, saved, tp_map, B, Lq, cfgs, extra=None):
+        """B: batch elements of the launch (all passes); cfgs: dropout-config function per pass."""
         VP, U32 = ctypes.c_void_p, ctypes.c_uint32
         nw, nb = self.P["infoGen.transformer.decoder.norm.weight"], self.P["infoGen.transformer.decoder.norm.bias"]
         ptr = lambda ts: [t.data_ptr() for t in ts]
-        if layer is None:                                                  # forward: both layers
-            s0, th, sc, sdev = self._dec_sites(0, cfg)
-            s1 = self._dec_sites(1, cfg)[0]
+        npass = len(cfgs)
+        if layer is None:                                                  # forward: both layers; sites [pass][layer][4]
+            s0, th, sc, sdev = self._dec_sites(0, cfgs)
+            s1 = self._dec_sites(1, cfgs)[0]
+            sites = [w for ps in range(npass) for sl in (s0, s1) for w in sl[4 * ps:4 * ps + 4]]
             fn(tgt, qp, dec_w, (VP * 2)(*ptr([kv[2] for kv in dec_kv])), (VP * 16)(*ptr(self._dec_params(0) + self._dec_params(1))), nw, nb,
-               (VP * 14)(*ptr(saved[0] + saved[1])), tp_map, B, Lq, (U32 * 8)(*(s0 + s1)), th, sc, sdev)
+               (VP * 14)(*ptr(saved[0] + saved[1])), tp_map, B, Lq, npass, (U32 * len(sites))(*sites), th, sc, sdev)
             return
         dt3_in, dtp, dtgt, dtgt_acc, dqp, dqp_acc, dY, kvpart, lnpart = extra
-        st, th, sc, sdev = self._dec_sites(layer, cfg)
+        st, th, sc, sdev = self._dec_sites(layer, cfgs)
         fn(layer, dt3_in, dtp, dec_w, dec_kv[layer][2], (VP * 8)(*ptr(self._dec_params(layer))), nw, (VP * 7)(*ptr(saved[layer])), dtgt, dtgt_acc,
-           dqp, dqp_acc, (VP * 4)(*ptr(dY)), kvpart, lnpart, B, Lq, (U32 * 4)(*st), th, sc, sdev)
+           dqp, dqp_acc, (VP * 4)(*ptr(dY)), kvpart, lnpart, B, Lq, npass, (U32 * len(st))(*st), th, sc, sdev)
 
-    def _dec_bwd_fused(self, dec, dtp, db1, dqp, dkin, dmem, kin, mem, B, Lq, cfg, G):
+    def _dec_bwd_fused(self, dec, dtp, db1, dqp, dkins, dmems, kins, mems, B, Lq, cfgs, G):
         """Backward of both decoder layers: two tatt_dec_bwd launches (layer 1, then layer 0 -- which adds its input gradient onto
         db1 and its query_pos gradient onto layer 1's), the reductions of their partials, and ONE grouped launch for the eight
-        [64,64] weight gradients."""
+        [64,64] weight gradients.  B: batch elements of all passes; kins / mems / dkins / dmems: per pass (keys = memory + pos)."""
         L, P, tr = self.L, self.P, "infoGen.transformer."
         _, dec_w, dec_kv, saved = dec
-        R0, Rt = B * Lq, B * 26
+        ng = len(cfgs)
+        R0, Rt, Rg = B * Lq, B * 26, (B // ng) * 26
         VP = ctypes.c_void_p
         dtgt1 = self.new(R0, 64)
         wg = []
@@ -609,12 +634,11 @@ class Engine:
             kvpart, lnpart = self.new(L.dec_bwd_kvpart_floats(B, Lq)), self.new(L.dec_bwd_lnpart_floats(B, Lq))
             if li == 0:
                 self._guard(db1)
-            self._dec_call(L.dec_bwd, li, None, None, dec_w, dec_kv, saved, None, B, Lq, cfg,
+            self._dec_call(L.dec_bwd, li, None, None, dec_w, dec_kv, saved, None, B, Lq, cfgs,
                            extra=(None if li == 1 else dtgt1, dtp, dtgt1 if li == 1 else db1, 0 if li == 1 else 1, dqp, 0 if li == 1 else 1,
                                   dY, kvpart, lnpart))
             L.dec_ln_final(lnpart, B, Lq, (VP * 6)(*[G[n].data_ptr() for n in (d + "norm2.weight", d + "norm2.bias", d + "norm3.weight", d + "norm3.bias",
                                                                             tr + "decoder.norm.weight", tr + "decoder.norm.bias")]))
-            Kp, Vp, _ = dec_kv[li]
             dKp, dVp = self.new(Rt, 64), self.new(Rt, 64)
             L.attn_kv_final(kvpart, Lq // 128, B, dKp, dVp, 0)
             W = P[d + "multihead_attn.in_proj_weight"]
@@ -624,9 +648,12 @@ class Engine:
                    (dY[1], c, G[d + "multihead_attn.out_proj.weight"], G[d + "multihead_attn.out_proj.bias"], R0, 64, 64, None, None, None),
                    (dY[2], t2, G[d + "linear1.weight"], G[d + "linear1.bias"], R0, 64, 64, None, None, None),
                    (dY[3], hd, G[d + "linear2.weight"], G[d + "linear2.bias"], R0, 64, 64, None, None, None)]
-            self.linear_dwb_group([(dKp, kin, dW[64:], db[64:], Rt, 64, 64, None, None, None), (dVp, mem, dW[128:], db[128:], Rt, 64, 64, None, None, None)])
-            self.linear_dx(dKp, W[64:], dkin, Rt, 64, 64, acc=0 if li == 1 else 1)
-            self.linear_dx(dVp, W[128:], dmem, Rt, 64, 64, acc=0 if li == 1 else 1)
+            for q in range(ng):                                            # key / value projections: per pass (their inputs differ by pass)
+                dK, dV = dKp[q * Rg:], dVp[q * Rg:]
+                self.linear_dwb_group([(dK, kins[q], dW[64:], db[64:], Rg, 64, 64, None, None, None),
+                                       (dV, mems[q], dW[128:], db[128:], Rg, 64, 64, None, None, None)])
+                self.linear_dx(dK, W[64:], dkins[q], Rg, 64, 64, acc=0 if li == 1 else 1)
+                self.linear_dx(dV, W[128:], dmems[q], Rg, 64, 64, acc=0 if li == 1 else 1)
         self.linear_dwb_group(wg)
 
     def ln_fwd(self, pre, x, res, cfg, R, save_v=True):
@@ -656,12 +683,12 @@ class Engine:
             names["stn_head.stn_convnet.0.0.weight"] = 1
         return names
 
-    def forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True, wpack=None, tp_ready=None, rpe_from=None):
+    def forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True, wpack=None, tp_ready=None, rpe_from=None, x2=None, seed2=1):
         if getattr(self.m, "in_planes", 4) == 4:
-            return self._forward(x, text_emb, training, seed, p_drop, want_ctx, wpack, tp_ready, rpe_from)
+            return self._forward(x, text_emb, training, seed, p_drop, want_ctx, wpack, tp_ready, rpe_from, x2, seed2)
         if x.dim() != 4 or tuple(x.shape[1:]) != (3, 16, 64):
             raise RuntimeError(f"expected LR input [B,3,16,64] (mask=False), got {tuple(x.shape)}")
-        if wpack is not None or rpe_from is not None:
+        if wpack is not None or rpe_from is not None or x2 is not None:
             raise NotImplementedError("mask=False: the two-pass (TSC) step is not wired up")
         self.refresh()
         orig = self.P
@@ -700,11 +727,17 @@ class Engine:
         for n, dim in names.items():
             G[n] += G4[n].narrow(dim, 0, 3)
 
-    def _forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True, wpack=None, tp_ready=None, rpe_from=None):
+    def _forward(self, x, text_emb, training, seed, p_drop=None, want_ctx=True, wpack=None, tp_ready=None, rpe_from=None, x2=None, seed2=1):
         """tp_ready: optional torch.cuda.Event after which `text_emb` may be read (the prior generator may still be running on
         another stream while the STN head, block1 and the RPE chain -- which do not need the prior -- are under way).
         wpack: the packed conv weights of an earlier forward call on the SAME weights (the TSC step runs the network
-        twice per optimiser step) — skips the repack."""
+        twice per optimiser step) — skips the repack.
+        x2 (with seed2): a SECOND input batch pushed through the network in the same launches -- the two SR passes of the TSC step
+        (interfaces/super_resolution_eng.py:233 and :259: same weights, same prior, pass 2 on the rotated LR image) as one batch of 2B
+        rows.  Per pass stay: BatchNorm batch statistics and running-statistic updates (pass 1 first, num_batches_tracked += 2), dropout
+        masks (seed / seed2, indices count within a pass), the STN head (BatchNorm over tiny maps: per-pass launches) and the text
+        branch (26 tokens per image: per-pass launches); the recurrent positional encoding is a function of the weights alone and is
+        computed once.  Returns sr [2B,4,32,128] (pass 1 first)."""
         L, m = self.L, self.m
         self.refresh()
         P = self.P
@@ -717,8 +750,17 @@ class Engine:
             raise RuntimeError(f"expected text prior [B,{K},1,26], got {tuple(text_emb.shape)}")
         x = x.detach().contiguous().float()
         text_emb = text_emb.detach().float()
+        ng = 1
+        xin = [x]
+        if x2 is not None:
+            if tuple(x2.shape) != tuple(x.shape) or not training or rpe_from is not None:
+                raise RuntimeError("x2: a second training-mode pass of the same shape (and no rpe_from)")
+            if not self.dec_fused or (B * H * W) % 128:
+                raise RuntimeError("two-pass batches need the fused decoder (TATT_DEC_FUSED) and B*H*W % 128 == 0")
+            ng, xin = 2, [x, x2.detach().contiguous().float()]
         p = (m.dropout_p if p_drop is None else p_drop) if training else 0.0
-        cfg = lambda site: self.dropcfg(site, seed, p)
+        seeds = [seed, seed2][:ng]
+        cfgs = [lambda site, s_=s_: self.dropcfg(site, s_, p) for s_ in seeds]
         ctx = Ctx()
         prec = getattr(m, "matmul_precision", "fp32")
         if prec not in ("fp32", "bf16", "f32x3"):
@@ -728,10 +770,12 @@ class Engine:
         # (bf16 mode: 6.77 -> 6.62 ms against fp32 MFMA on those launches, same error as before: 6.1e-3 max-abs at B=4)
         self.pl = self.px = ctx["pl"] = 0 if prec == "fp32" else 4
         ctx["meta"] = (B, training, seed, p)
+        ctx["ng"], ctx["seeds"] = ng, seeds
         self.wpack = ctx["wpack"] = {} if wpack is None else wpack   # weights change every step: repacked per forward call
-        R0 = B * H * W
+        Bt = ng * B                                                  # images in the batched launches
+        R0, Ra = B * H * W, Bt * H * W                               # rows of one pass / of the batch
         use_stn = bool(m.stn and training)
-        ctx["x"] = x
+        ctx["x"] = xin
 
         # ---- recurrent positional encoding (model/transformer_v2.py:215-221): GRU over the batch axis, identical input at
         # every step.  It depends on weights only and is a chain of B dependent, latency-bound launches, so it is forked
@@ -746,7 +790,7 @@ class Engine:
             # to that pass (ctx["rpe_owner"]) instead of running a BPTT chain of its own -- the chain is linear in that gradient.
             if rpe_from["meta"][0] != B or rpe_from.get("rpe_owner") is not None:
                 raise RuntimeError("rpe_from must be the context of a forward pass of this step with the same batch size that ran the RPE itself")
-            xg, gi, hstep, gh_all, qp = (rpe_from["tp"][i] for i in (4, 5, 6, 7, 8))
+            xg, gi, hstep, gh_all, qp = rpe_from["rpe"]
             ctx["rpe_owner"] = rpe_from
             rpe_from["rpe_lent"] = True
         else:
@@ -777,11 +821,13 @@ class Engine:
                     for s in range(B):  # one fused launch per step: h_s W_hh^T, gates, h_{s+1}, query_pos (tatt_rpe_step_fwd)
                         L.rpe_step_fwd(gi, whh_f, whh_b, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], hstep[0, s + 1],
                                        gh_all[0, s], qp, s, B, dsg, dsh)
+        ctx["rpe"] = (xg, gi, hstep, gh_all, qp)
 
         # ---- text branch of the TP interpreter (fc_in, PReLU, positional encoding, encoder layer): it reads the prior and weights
         # only, so it runs on a stream of its own beside the STN head / block1 (and the RPE chain) until the decoder needs it
         enc = self.enc_stream() if tp_ready is None else main    # (with a prior still in flight there are enough strands already:
         enc.wait_stream(main)                                    #  the whole-iteration step got slower with one more)
+        fused = self.dec_fused and (H * W) % 128 == 0
         with torch.cuda.stream(enc):
             Rt = B * 26
             tpr = self.new(Rt, K)
@@ -792,20 +838,22 @@ class Engine:
             self.linear(tpr, P[ig + "fc_in.weight"], P[ig + "fc_in.bias"], t0, Rt, 64, K)
             t = self.new(Rt, 64)
             L.prelu_fwd(t0, P[ig + "activation.weight"], t, Rt * 64)
-            pos = self.new(Rt, 64)
-            L.pe_dropout(P[ig + "pe.pe"], pos, B, 26, *cfg("pe"))
-            # encoder layer (input doubled, model/transformer_v2.py:273)
+            src2 = self.new(Rt, 64)
+            L.axpby(t, 2.0, None, 0.0, src2, Rt * 64, 0)             # encoder input doubled (model/transformer_v2.py:273)
             e = tr + "encoder.layers.0."
-            src2, qk = self.new(Rt, 64), self.new(Rt, 64)
-            L.axpby(t, 2.0, None, 0.0, src2, Rt * 64, 0)
-            L.axpby(src2, 1.0, pos, 1.0, qk, Rt * 64, 0)
-            a_e, att_e = self.mha_fwd(e + "self_attn.", qk, qk, src2, B, 26, cfg("enc_attn"))
-            s1, v1e = self.ln_fwd(e + "norm1.", src2, a_e, cfg("enc_drop1"), Rt)
-            f_e, ffn_e = self.ffn_fwd(e, s1, Rt, cfg("enc_ffn"))
-            mem, v2e = self.ln_fwd(e + "norm2.", s1, f_e, cfg("enc_drop2"), Rt)
-            kin = self.new(Rt, 64)
-            L.axpby(mem, 1.0, pos, 1.0, kin, Rt * 64, 0)
-            fused = self.dec_fused and (H * W) % 128 == 0
+            text = []                                                # per pass: the dropout masks differ
+            for cfg in cfgs:
+                pos = self.new(Rt, 64)
+                L.pe_dropout(P[ig + "pe.pe"], pos, B, 26, *cfg("pe"))
+                qk = self.new(Rt, 64)
+                L.axpby(src2, 1.0, pos, 1.0, qk, Rt * 64, 0)
+                a_e, att_e = self.mha_fwd(e + "self_attn.", qk, qk, src2, B, 26, cfg("enc_attn"))
+                s1, v1e = self.ln_fwd(e + "norm1.", src2, a_e, cfg("enc_drop1"), Rt)
+                f_e, ffn_e = self.ffn_fwd(e, s1, Rt, cfg("enc_ffn"))
+                mem, v2e = self.ln_fwd(e + "norm2.", s1, f_e, cfg("enc_drop2"), Rt)
+                kin = self.new(Rt, 64)
+                L.axpby(mem, 1.0, pos, 1.0, kin, Rt * 64, 0)
+                text.append((pos, qk, att_e, v1e, s1, ffn_e, v2e, mem, kin))
             if fused:
                 # fused decoder (tatt_dec_fwd): the projected keys / values of both layers and the MFMA-order operand packs belong to
                 # the text branch -- they need the encoder memory and weights only
@@ -817,11 +865,12 @@ class Engine:
                 dec_kv = []
                 for d_ in dl:
                     Wi, bi = P[d_ + "multihead_attn.in_proj_weight"], P[d_ + "multihead_attn.in_proj_bias"]
-                    Kp, Vp = self.new(Rt, 64), self.new(Rt, 64)
-                    self.linear(kin, Wi[64:], bi[64:], Kp, Rt, 64, 64)
-                    self.linear(mem, Wi[128:], bi[128:], Vp, Rt, 64, 64)
-                    tab = self.new(L.dec_kv_table_floats(B))
-                    L.dec_pack_kv(Kp, Vp, tab, B)
+                    Kp, Vp = self.new(ng * Rt, 64), self.new(ng * Rt, 64)
+                    for q_, tx in enumerate(text):
+                        self.linear(tx[8], Wi[64:], bi[64:], Kp[q_ * Rt:], Rt, 64, 64)
+                        self.linear(tx[7], Wi[128:], bi[128:], Vp[q_ * Rt:], Rt, 64, 64)
+                    tab = self.new(L.dec_kv_table_floats(Bt))
+                    L.dec_pack_kv(Kp, Vp, tab, Bt)
                     dec_kv.append((Kp, Vp, tab))
 
         # per-step weight packs of the main strand (conv weights in MFMA order, 1x1 conv folded into the GRU projections): issued
@@ -829,10 +878,16 @@ class Engine:
         self._prepack(use_stn)
         self._gru_fold()
 
-        # ---- STN head + TPS rectification (model/tsrn.py:655-657) ------------------------------------------
-        if use_stn:
+        # ---- STN head + TPS rectification (model/tsrn.py:655-657), per pass --------------------------------
+        xs = self.new(Ra, 4)
+        stn_ctx = []
+        for q_, xq in enumerate(xin):
+            xs_q = xs[q_ * R0:]
+            if not use_stn:
+                L.nchw_to_nhwc(xq, xs_q, B, 4, H * W)
+                continue
             xn = self.new(R0, 4)
-            L.nchw_to_nhwc(x, xn, B, 4, H * W)
+            L.nchw_to_nhwc(xq, xn, B, 4, H * W)
             h, hh, ww = xn, H, W
             stn_saved = []
             for (idx, cin, cout, pool) in STN_STAGES:
@@ -861,26 +916,25 @@ class Engine:
             Tm = self.new(H * W, 20)                                          # target_coordinate_repr @ inverse_kernel[:, :20]
             L.gemm(P["tps.target_coordinate_repr"], P["tps.inverse_kernel"], Tm, None, H * W, 20, 23, 23, 1, 1, 23, 20,
                    1, 0, 0, 0, 0, 0, 1, None)
-            xs = self.new(R0, 4)
-            L.tps_sample_fwd(x, ctrl, Tm, xs, None, B, 4, H, W)
-            ctx["stn"] = (stn_saved, f, l1, stat1, feat01, ctrl, Tm)
-        else:
-            xs = self.new(R0, 4)
-            L.nchw_to_nhwc(x, xs, B, 4, H * W)
+            L.tps_sample_fwd(xq, ctrl, Tm, xs_q, None, B, 4, H, W)
+            stn_ctx.append((stn_saved, f, l1, stat1, feat01, ctrl, Tm))
+        if use_stn:
+            ctx["stn_all"] = stn_ctx
+            ctx["stn"] = stn_ctx[0]
         ctx["xs"] = xs
 
         # ---- block1: conv9x9 + PReLU -----------------------------------------------------------------------------
-        c1 = self.new(R0, 64)
-        self.conv(xs, P["block1.0.weight"], P["block1.0.bias"], c1, B, H, W, 4, 64, 9)
-        b1 = self.new(R0, 64)
-        L.prelu_fwd(c1, P["block1.1.weight"], b1, R0 * 64)
+        c1 = self.new(Ra, 64)
+        self.conv(xs, P["block1.0.weight"], P["block1.0.bias"], c1, Bt, H, W, 4, 64, 9)
+        b1 = self.new(Ra, 64)
+        L.prelu_fwd(c1, P["block1.1.weight"], b1, Ra * 64)
         ctx["c1"], ctx["b1"] = c1, b1
 
         # The first SRB's convolutions (conv-BN-mish-conv-BN, model/tsrn.py:333-338) need block1's output only: they go here,
         # ahead of the decoder, where the main chain would otherwise sit waiting for the RPE chain's query_pos.
         def srb_convs(pre, blk):
-            ca, ma, st1 = self.conv_bn(pre + "bn1.", blk, P[pre + "conv1.weight"], P[pre + "conv1.bias"], B, H, W, 64, 64, 3, training, 2)
-            cb, r2, st2 = self.conv_bn(pre + "bn2.", ma, P[pre + "conv2.weight"], P[pre + "conv2.bias"], B, H, W, 64, 64, 3, training, 0)
+            ca, ma, st1 = self.conv_bn(pre + "bn1.", blk, P[pre + "conv1.weight"], P[pre + "conv1.bias"], Bt, H, W, 64, 64, 3, training, 2, ng=ng)
+            cb, r2, st2 = self.conv_bn(pre + "bn2.", ma, P[pre + "conv2.weight"], P[pre + "conv2.bias"], Bt, H, W, 64, 64, 3, training, 0, ng=ng)
             return ca, ma, st1, cb, r2, st2
         first_convs = srb_convs("block2.", b1) if m.srb_nums > 0 else None
 
@@ -890,14 +944,16 @@ class Engine:
         main.wait_stream(side)                                                # join the RPE chain: query_pos is needed now
         tgt = b1
         dec = []
-        tp_map = self.new(R0, 64)
+        tp_map = self.new(Ra, 64)
         if fused:
             if want_ctx:
-                saved = [[self.new(R0, 64) for _ in range(7)] for _ in range(2)]
+                saved = [[self.new(Ra, 64) for _ in range(7)] for _ in range(2)]
             else:                                                         # nobody reads them: one scratch tensor takes all the stores
-                saved = [[self.new(R0, 64)] * 7] * 2
-            self._dec_call(L.dec_fwd, None, b1, qp, dec_w, dec_kv, saved, tp_map, B, H * W, cfg)
+                saved = [[self.new(Ra, 64)] * 7] * 2
+            self._dec_call(L.dec_fwd, None, b1, qp, dec_w, dec_kv, saved, tp_map, Bt, H * W, cfgs)
             dec = ("fused", dec_w, dec_kv, saved)
+        pos, qk, att_e, v1e, s1, ffn_e, v2e, mem, kin = text[0]
+        cfg = cfgs[0]
         for li in range(0 if fused else 2):
             d = f"{tr}decoder.layers.{li}."
             qin = self.new(R0, 64)
@@ -911,6 +967,7 @@ class Engine:
             dec.append((tgt, qin, att, v2, t2, ffn, v3, t3))
             tgt = t3
         ctx["tp"] = (tpr, t0, t, pos, xg, gi, hstep, gh_all, qp, src2, qk, att_e, v1e, s1, ffn_e, v2e, mem, kin, dec)
+        ctx["text"] = text
         ctx["tp_map"] = tp_map
 
         # ---- SRBs (model/tsrn.py:883-901) ----------------------------------------------------------------------------
@@ -919,32 +976,36 @@ class Engine:
         for i in range(m.srb_nums):
             pre = f"block{i + 2}."
             ca, ma, st1, cb, r2, st2 = first_convs if i == 0 else srb_convs(pre, blk)
-            r = self.gru_block_fwd(pre + "gru1.", [r2, tp_map], B, H, W, True, want_ctx, ctx, pre + "gru1")
-            s = self.new(R0, 64)
-            L.axpby(blk, 1.0, r, 1.0, s, R0 * 64, 0)
-            out = self.gru_block_fwd(pre + "gru2.", [s], B, H, W, False, want_ctx, ctx, pre + "gru2")
+            r = self.gru_block_fwd(pre + "gru1.", [r2, tp_map], Bt, H, W, True, want_ctx, ctx, pre + "gru1")
+            s = self.new(Ra, 64)
+            L.axpby(blk, 1.0, r, 1.0, s, Ra * 64, 0)
+            out = self.gru_block_fwd(pre + "gru2.", [s], Bt, H, W, False, want_ctx, ctx, pre + "gru2")
             srbs.append((blk, ca, st1, ma, cb, st2, r2, s))
             blk = out
         ctx["srbs"] = srbs
 
         # ---- block7 (conv+BN) + global residual, block8 (upsample + 9x9) + sigmoid ---------------------------------------
         k7 = f"block{m.srb_nums + 2}."
-        c7, u_in, st7 = self.conv_bn(k7 + "1.", blk, P[k7 + "0.weight"], P[k7 + "0.bias"], B, H, W, 64, 64, 3, training, 0, res=b1)
+        c7, u_in, st7 = self.conv_bn(k7 + "1.", blk, P[k7 + "0.weight"], P[k7 + "0.bias"], Bt, H, W, 64, 64, 3, training, 0, res=b1, ng=ng)
         k8 = f"block{m.srb_nums + 3}."
-        cu = self.new(R0, 256)
-        self.conv(u_in, P[k8 + "0.conv.weight"], P[k8 + "0.conv.bias"], cu, B, H, W, 64, 256, 3)
-        up = self.new(4 * R0, 64)
-        L.pixshuf_mish_fwd(cu, up, B, H, W, 64)
-        pre_s = self.new(4 * R0, 4)
+        cu = self.new(Ra, 256)
+        self.conv(u_in, P[k8 + "0.conv.weight"], P[k8 + "0.conv.bias"], cu, Bt, H, W, 64, 256, 3)
+        up = self.new(4 * Ra, 64)
+        L.pixshuf_mish_fwd(cu, up, Bt, H, W, 64)
+        pre_s = self.new(4 * Ra, 4)
         # the output convolution feeds the sigmoid directly (no normalisation behind it to absorb operand rounding): fp32 in both modes
-        self.conv(up, P[k8 + "1.weight"], P[k8 + "1.bias"], pre_s, B, 2 * H, 2 * W, 64, 4, 9, fp32=True)
-        sr = self.new(B, 4, 2 * H, 2 * W)
-        L.sigmoid_to_nchw(pre_s, sr, B, 4, 4 * H * W)
+        self.conv(up, P[k8 + "1.weight"], P[k8 + "1.bias"], pre_s, Bt, 2 * H, 2 * W, 64, 4, 9, fp32=True)
+        sr = self.new(Bt, 4, 2 * H, 2 * W)
+        L.sigmoid_to_nchw(pre_s, sr, Bt, 4, 4 * H * W)
         ctx["tail"] = (blk, c7, st7, u_in, cu, up, pre_s)
         ctx["sr"] = sr
         ctx["use_stn"] = use_stn
-        if self._nbt:
-            torch._foreach_add_(self._nbt, 1)
+        if self._nbt:                                         # one fused launch; a two-pass batch counts every BatchNorm twice
+            uniq = {}
+            for t_ in self._nbt:
+                uniq.setdefault(t_.data_ptr(), [t_, 0])[1] += 1
+            for n_ in set(c_ for _, c_ in uniq.values()):
+                torch._foreach_add_([t_ for t_, c_ in uniq.values() if c_ == n_], n_)
             self._nbt = []
         return sr, ctx
 
@@ -989,31 +1050,36 @@ class Engine:
             L.axpby(x, a, y, b, out, n, accumulate)
         L, m, P = self.L, self.m, self.P
         B, training, seed, p = ctx["meta"]
+        ng, seeds = ctx.get("ng", 1), ctx.get("seeds", [seed])    # ng = 2: a two-pass batch (forward(x2=...)); B is the size of ONE pass
         self.pf, self.pl = ctx["pf"], ctx.get("pl", 0)
         self.px = self.pl
         self.wpack = ctx["wpack"]
-        cfg = lambda site: self.dropcfg(site, seed, p)
+        cfgs = [lambda site, s_=s_: self.dropcfg(site, s_, p) for s_ in seeds]
+        cfg = cfgs[0]
         H, W = 16, 64
-        R0 = B * H * W
+        Bt = ng * B
+        R0, Ra = B * H * W, Bt * H * W
         dsr = dsr.contiguous().float()
+        if dsr.shape[0] != Bt:
+            raise RuntimeError(f"backward: gradient of {dsr.shape[0]} images for a forward pass of {Bt}")
         blk_last, c7, st7, u_in, cu, up, pre_s = ctx["tail"]
         b1, c1, tp_map = ctx["b1"], ctx["c1"], ctx["tp_map"]
         k7, k8 = f"block{m.srb_nums + 2}.", f"block{m.srb_nums + 3}."
 
         # ---- tail ------------------------------------------------------------------------------------------------
-        dpre = self.new(4 * R0, 4)
-        L.sigmoid_bwd_to_nhwc(ctx["sr"], dsr, dpre, B, 4, 4 * H * W)
-        self.conv_wgrad(up, dpre, G[k8 + "1.weight"], G[k8 + "1.bias"], B, 2 * H, 2 * W, 64, 4, 9, fp32=True)
-        dup = self.new(4 * R0, 64)
-        self.conv_dgrad(dpre, P[k8 + "1.weight"], dup, B, 2 * H, 2 * W, 64, 4, 9, fp32=True)
-        dcu = self.new(R0, 256)
-        L.pixshuf_mish_bwd(cu, dup, dcu, B, H, W, 64)
-        self.conv_wgrad(u_in, dcu, G[k8 + "0.conv.weight"], G[k8 + "0.conv.bias"], B, H, W, 64, 256, 3)
+        dpre = self.new(4 * Ra, 4)
+        L.sigmoid_bwd_to_nhwc(ctx["sr"], dsr, dpre, Bt, 4, 4 * H * W)
+        self.conv_wgrad(up, dpre, G[k8 + "1.weight"], G[k8 + "1.bias"], Bt, 2 * H, 2 * W, 64, 4, 9, fp32=True)
+        dup = self.new(4 * Ra, 64)
+        self.conv_dgrad(dpre, P[k8 + "1.weight"], dup, Bt, 2 * H, 2 * W, 64, 4, 9, fp32=True)
+        dcu = self.new(Ra, 256)
+        L.pixshuf_mish_bwd(cu, dup, dcu, Bt, H, W, 64)
+        self.conv_wgrad(u_in, dcu, G[k8 + "0.conv.weight"], G[k8 + "0.conv.bias"], Bt, H, W, 64, 256, 3)
         # grad of block1's output (accumulated below) = grad of u_in = bn(c7) + b1: the BatchNorm's reduction runs in the dgrad epilogue
-        db1, dc7 = self.conv_dgrad_bn(dcu, P[k8 + "0.conv.weight"], B, H, W, 64, 256, 3, k7 + "1.", c7, st7, 0, training, G)
-        self.conv_wgrad(blk_last, dc7, G[k7 + "0.weight"], G[k7 + "0.bias"], B, H, W, 64, 64, 3, bias_grad=not training)
-        dout = self.new(R0, 64)
-        self.conv_dgrad(dc7, P[k7 + "0.weight"], dout, B, H, W, 64, 64, 3)
+        db1, dc7 = self.conv_dgrad_bn(dcu, P[k8 + "0.conv.weight"], Bt, H, W, 64, 256, 3, k7 + "1.", c7, st7, 0, training, G, ng=ng)
+        self.conv_wgrad(blk_last, dc7, G[k7 + "0.weight"], G[k7 + "0.bias"], Bt, H, W, 64, 64, 3, bias_grad=not training)
+        dout = self.new(Ra, 64)
+        self.conv_dgrad(dc7, P[k7 + "0.weight"], dout, Bt, H, W, 64, 64, 3)
         on_stage("tail")
 
         # ---- SRBs, last to first ----------------------------------------------------------------------------------
@@ -1024,37 +1090,46 @@ class Engine:
         for pre, n_ in sizes.items():
             self._gru_gtmp[pre] = gbuf[o:o + n_]
             o += n_
-        dtp = self.new(R0, 64)
+        dtp = self.new(Ra, 64)
         first_tp = True
         for i in reversed(range(m.srb_nums)):
             pre = f"block{i + 2}."
             blk, ca, st1, ma, cb, st2, r2, s = ctx["srbs"][i]
-            ds = self.new(R0, 64)
-            self.gru_block_bwd(pre + "gru2.", dout, [(s, ds, 0)], B, H, W, False, ctx, pre + "gru2", G)
-            dr2 = self.new(R0, 64)
-            part, nblk = self.gru_block_bwd(pre + "gru1.", ds, [(r2, dr2, 0), (tp_map, dtp, 0 if first_tp else 1)], B, H, W,
-                                            True, ctx, pre + "gru1", G, bn=(pre + "bn2.", cb, st2))
+            ds = self.new(Ra, 64)
+            self.gru_block_bwd(pre + "gru2.", dout, [(s, ds, 0)], Bt, H, W, False, ctx, pre + "gru2", G)
+            dr2 = self.new(Ra, 64)
+            parts, nblk = self.gru_block_bwd(pre + "gru1.", ds, [(r2, dr2, 0), (tp_map, dtp, 0 if first_tp else 1)], Bt, H, W,
+                                             True, ctx, pre + "gru1", G, bn=(pre + "bn2.", cb, st2), ng=ng)
             first_tp = False
             self._w_flush()
-            dcb = self.bn_bwd_part(pre + "bn2.", cb, dr2, st2, part, nblk, R0, 64, training, G)
-            self.conv_wgrad(ma, dcb, G[pre + "conv2.weight"], G[pre + "conv2.bias"], B, H, W, 64, 64, 3, bias_grad=not training)
-            _, dca = self.conv_dgrad_bn(dcb, P[pre + "conv2.weight"], B, H, W, 64, 64, 3, pre + "bn1.", ca, st1, 2, training, G)
-            self.conv_wgrad(blk, dca, G[pre + "conv1.weight"], G[pre + "conv1.bias"], B, H, W, 64, 64, 3, bias_grad=not training)
-            self.conv_dgrad(dca, P[pre + "conv1.weight"], ds, B, H, W, 64, 64, 3, acc=1)     # dx = ds + conv1^T(dca)
+            if ng == 1:
+                dcb = self.bn_bwd_part(pre + "bn2.", cb, dr2, st2, parts, nblk, R0, 64, training, G)
+            else:
+                dcb = self.new(Ra, 64)
+                for q_ in range(ng):
+                    self.bn_bwd_part(pre + "bn2.", cb[q_ * R0:], dr2[q_ * R0:], st2[q_], parts[q_], nblk, R0, 64, training, G, dx=dcb[q_ * R0:])
+            self.conv_wgrad(ma, dcb, G[pre + "conv2.weight"], G[pre + "conv2.bias"], Bt, H, W, 64, 64, 3, bias_grad=not training)
+            _, dca = self.conv_dgrad_bn(dcb, P[pre + "conv2.weight"], Bt, H, W, 64, 64, 3, pre + "bn1.", ca, st1, 2, training, G, ng=ng)
+            self.conv_wgrad(blk, dca, G[pre + "conv1.weight"], G[pre + "conv1.bias"], Bt, H, W, 64, 64, 3, bias_grad=not training)
+            self.conv_dgrad(dca, P[pre + "conv1.weight"], ds, Bt, H, W, 64, 64, 3, acc=1)     # dx = ds + conv1^T(dca)
             dout = ds                                            # (no flush here: the conv weight gradients wait for the next SRB's
-        axpby(dout, 1.0, None, 0.0, db1, R0 * 64, 1)             #  flush, past its latency-bound GRU kernels: 9.48 -> 9.41 ms)
+        axpby(dout, 1.0, None, 0.0, db1, Ra * 64, 1)             #  flush, past its latency-bound GRU kernels: 9.48 -> 9.41 ms)
         on_stage("srbs")
 
         # ---- TP interpreter --------------------------------------------------------------------------------------
         ig, tr = "infoGen.", "infoGen.transformer."
-        (tpr, t0, t, pos, xg, gi, hstep, gh_all, qp, src2, qk, att_e, v1e, s1, ffn_e, v2e, mem, kin, dec) = ctx["tp"]
+        (tpr, t0, t, _, xg, gi, hstep, gh_all, qp, src2, _, _, _, _, _, _, _, _, dec) = ctx["tp"]
+        text = ctx["text"]                                                     # per pass: (pos, qk, att_e, v1e, s1, ffn_e, v2e, mem, kin)
         Rt, K = B * 26, m.text_embedding
-        dqp = self.new(R0, 64)
-        dmem, dkin = self.new(Rt, 64), self.new(Rt, 64)
+        dqp = self.new(Ra, 64)
+        dmems, dkins = [self.new(Rt, 64) for _ in range(ng)], [self.new(Rt, 64) for _ in range(ng)]
         dnext = None                                                           # grad flowing into layer li's output from above
         fused = len(dec) > 0 and isinstance(dec[0], str)
         if fused:
-            self._dec_bwd_fused(dec, dtp, db1, dqp, dkin, dmem, kin, mem, B, H * W, cfg, G)
+            self._dec_bwd_fused(dec, dtp, db1, dqp, dkins, dmems, [tx[8] for tx in text], [tx[7] for tx in text], Bt, H * W, cfgs, G)
+            if ng == 2:                                                        # both passes read the same query_pos
+                axpby(dqp[R0:], 1.0, None, 0.0, dqp, R0 * 64, 1)
+        kin, mem, dkin, dmem = text[0][8], text[0][7], dkins[0], dmems[0]
         for li in (() if fused else (1, 0)):
             d = f"{tr}decoder.layers.{li}."
             tgt, qin, att, v2, t2, ffn, v3, t3 = dec[li]
@@ -1074,7 +1149,8 @@ class Engine:
             dnext = dtgt
         if not fused:
             axpby(dnext, 1.0, None, 0.0, db1, R0 * 64, 1)
-        axpby(dkin, 1.0, None, 0.0, dmem, Rt * 64, 1)                     # kin = mem + pos
+        for q_ in range(ng):
+            axpby(dkins[q_], 1.0, None, 0.0, dmems[q_], Rt * 64, 1)           # kin = mem + pos
         # (no flush here: the decoder's and the encoder's weight gradients stay queued until rpe_finish() -- bulk kernels beside the
         #  RPE chain slow its 64 latency-bound steps down by more than the overlap returns: 9.51 -> 9.45 ms)
         # recurrent positional encoding, BPTT over the batch axis: dqp is complete here.  The chain of B latency-bound
@@ -1121,17 +1197,23 @@ class Engine:
                 self.colsum(dgi_sum[dd], 64, 1536, G[g + "bias_ih_l0" + sfx])
                 self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd, splitk=8, fp32=True)
             L.rpe_scatter_dx(dxg, G[ig + "init_factor.weight"], 1)
-        # encoder
+        # encoder, per pass (the text branch runs once per pass: its dropout masks differ); the passes' gradients wrt the doubled
+        # encoder input (shared) are summed
         e = tr + "encoder.layers.0."
-        ds1 = self.new(Rt, 64)
-        dfe = self.ln_bwd(e + "norm2.", v2e, dmem, 1.0, ds1, 0, cfg("enc_drop2"), Rt, G, True)
-        self.ffn_bwd(e, dfe if dfe is not None else ds1, ffn_e, s1, Rt, cfg("enc_ffn"), G, ds1)
         dsrc2 = self.new(Rt, 64)
-        dae = self.ln_bwd(e + "norm1.", v1e, ds1, 1.0, dsrc2, 0, cfg("enc_drop1"), Rt, G, True)
-        dqk = self.new(Rt, 64)
-        self.mha_bwd(e + "self_attn.", dae if dae is not None else dsrc2, att_e, qk, qk, src2, B, 26, cfg("enc_attn"), G,
-                     dqk, dqk, dsrc2, 0, 1, 1)
-        axpby(dqk, 1.0, None, 0.0, dsrc2, Rt * 64, 1)
+        for q_, (pos, qk, att_e, v1e, s1, ffn_e, v2e, mem, kin) in enumerate(text):
+            cf = cfgs[q_]
+            ds1 = self.new(Rt, 64)
+            dfe = self.ln_bwd(e + "norm2.", v2e, dmems[q_], 1.0, ds1, 0, cf("enc_drop2"), Rt, G, True)
+            self.ffn_bwd(e, dfe if dfe is not None else ds1, ffn_e, s1, Rt, cf("enc_ffn"), G, ds1)
+            dsq = dsrc2 if q_ == 0 else self.new(Rt, 64)
+            dae = self.ln_bwd(e + "norm1.", v1e, ds1, 1.0, dsq, 0, cf("enc_drop1"), Rt, G, True)
+            dqk = self.new(Rt, 64)
+            self.mha_bwd(e + "self_attn.", dae if dae is not None else dsq, att_e, qk, qk, src2, B, 26, cf("enc_attn"), G,
+                         dqk, dqk, dsq, 0, 1, 1)
+            axpby(dqk, 1.0, None, 0.0, dsq, Rt * 64, 1)
+            if q_ > 0:
+                axpby(dsq, 1.0, None, 0.0, dsrc2, Rt * 64, 1)
         dt = self.new(Rt, 64)
         axpby(dsrc2, 2.0, None, 0.0, dt, Rt * 64, 0)
         dt0 = self.new(Rt, 64)
@@ -1139,55 +1221,56 @@ class Engine:
         self.linear_dwb(dt0, tpr, G[ig + "fc_in.weight"], G[ig + "fc_in.bias"], Rt, 64, K)
 
         # ---- block1 ------------------------------------------------------------------------------------------------
-        dc1 = self.new(R0, 64)
-        L.prelu_bwd(c1, P["block1.1.weight"], db1, dc1, G["block1.1.weight"], 1, R0 * 64, self.ws)
+        dc1 = self.new(Ra, 64)
+        L.prelu_bwd(c1, P["block1.1.weight"], db1, dc1, G["block1.1.weight"], 1, Ra * 64, self.ws)
         xs = ctx["xs"]
-        self.conv_wgrad(xs, dc1, G["block1.0.weight"], G["block1.0.bias"], B, H, W, 4, 64, 9)
+        self.conv_wgrad(xs, dc1, G["block1.0.weight"], G["block1.0.bias"], Bt, H, W, 4, 64, 9)
         if not ctx["use_stn"]:
             rpe_finish()
             on_stage("head")
             on_stage("infogen")
             return
-        # ---- TPS + STN head ----------------------------------------------------------------------------------------
-        stn_saved, f, l1, stat1, feat01, ctrl, Tm = ctx["stn"]
-        dxs = self.new(R0, 4)
-        self.conv_dgrad(dc1, P["block1.0.weight"], dxs, B, H, W, 4, 64, 9, fp32=True)
-        dctrl = self.new(B, 40)
-        L.tps_sample_bwd(ctx["x"], ctrl, Tm, dxs, dctrl, B, 4, H, W, 0)
-        # The RPE chain (forked after the decoder) has ended by now at the benchmark shapes: its input-gradient GEMMs go here and
-        # its weight gradients join the queue, so that they overlap with the STN head's backward pass instead of trailing it.
-        rpe_finish()
-        self._w_flush()
-        self.linear_dw(dctrl, feat01, G["stn_head.stn_fc2.weight"], B, 40, 512, fp32=True)
-        self.colsum(dctrl, B, 40, G["stn_head.stn_fc2.bias"])
-        dfeat = self.new(B, 512)
-        self.linear_dx(dctrl, P["stn_head.stn_fc2.weight"], dfeat, B, 40, 512, fp32=True)
-        axpby(dfeat, 0.1, None, 0.0, dfeat, B * 512, 0)
-        dl1 = self.bn_bwd("stn_head.stn_fc1.1.", l1, dfeat, stat1, B, 512, 1, True, G)
-        self.linear_dw(dl1, f, G["stn_head.stn_fc1.0.weight"], B, 512, 512, fp32=True)
-        self.colsum(dl1, B, 512, G["stn_head.stn_fc1.0.bias"])
-        df = self.new(B, 512)
-        self.linear_dx(dl1, P["stn_head.stn_fc1.0.weight"], df, B, 512, 512, fp32=True)
-        dh = self.new(B * 2, 256)
-        L.nchw_to_nhwc(df, dh, B, 256, 2)
-        for (idx, cin, cout, pool), rec in zip(reversed(STN_STAGES), reversed(stn_saved)):
-            pre = f"stn_head.stn_convnet.{idx}."
-            hin, c, stat, a, hh, ww = rec
-            Rr = B * hh * ww
-            if pool is not None:
-                da = self.new(Rr, cout)
-                L.maxpool_bwd(a, dh, da, B, hh, ww, cout, pool[0], pool[1])
-            else:
-                da = dh
-            dc = self.bn_bwd(pre + "1.", c, da, stat, Rr, cout, 1, True, G)
-            if self.debug is not None:
-                self.debug[f"stn{idx}"] = (dh.clone(), da.clone(), dc.clone())
-            self.conv_wgrad(hin, dc, G[pre + "0.weight"], G[pre + "0.bias"], B, hh, ww, cin, cout, 3, fp32=True, bias_grad=False)  # BN in training mode
-            if idx > 0:
-                dh = self.new(Rr, cin)
-                self.conv_dgrad(dc, P[pre + "0.weight"], dh, B, hh, ww, cin, cout, 3, fp32=True)
-            if idx in (8, 4):
+        # ---- TPS + STN head, per pass ------------------------------------------------------------------------------
+        dxs = self.new(Ra, 4)
+        self.conv_dgrad(dc1, P["block1.0.weight"], dxs, Bt, H, W, 4, 64, 9, fp32=True)
+        for q_, (stn_saved, f, l1, stat1, feat01, ctrl, Tm) in enumerate(ctx["stn_all"]):
+            dctrl = self.new(B, 40)
+            L.tps_sample_bwd(ctx["x"][q_], ctrl, Tm, dxs[q_ * R0:], dctrl, B, 4, H, W, 0)
+            if q_ == 0:
+                # The RPE chain (forked after the decoder) has ended by now at the benchmark shapes: its input-gradient GEMMs go here and
+                # its weight gradients join the queue, so that they overlap with the STN head's backward pass instead of trailing it.
+                rpe_finish()
                 self._w_flush()
+            self.linear_dw(dctrl, feat01, G["stn_head.stn_fc2.weight"], B, 40, 512, fp32=True)
+            self.colsum(dctrl, B, 40, G["stn_head.stn_fc2.bias"])
+            dfeat = self.new(B, 512)
+            self.linear_dx(dctrl, P["stn_head.stn_fc2.weight"], dfeat, B, 40, 512, fp32=True)
+            axpby(dfeat, 0.1, None, 0.0, dfeat, B * 512, 0)
+            dl1 = self.bn_bwd("stn_head.stn_fc1.1.", l1, dfeat, stat1, B, 512, 1, True, G)
+            self.linear_dw(dl1, f, G["stn_head.stn_fc1.0.weight"], B, 512, 512, fp32=True)
+            self.colsum(dl1, B, 512, G["stn_head.stn_fc1.0.bias"])
+            df = self.new(B, 512)
+            self.linear_dx(dl1, P["stn_head.stn_fc1.0.weight"], df, B, 512, 512, fp32=True)
+            dh = self.new(B * 2, 256)
+            L.nchw_to_nhwc(df, dh, B, 256, 2)
+            for (idx, cin, cout, pool), rec in zip(reversed(STN_STAGES), reversed(stn_saved)):
+                pre = f"stn_head.stn_convnet.{idx}."
+                hin, c, stat, a, hh, ww = rec
+                Rr = B * hh * ww
+                if pool is not None:
+                    da = self.new(Rr, cout)
+                    L.maxpool_bwd(a, dh, da, B, hh, ww, cout, pool[0], pool[1])
+                else:
+                    da = dh
+                dc = self.bn_bwd(pre + "1.", c, da, stat, Rr, cout, 1, True, G)
+                if self.debug is not None:
+                    self.debug[f"stn{idx}"] = (dh.clone(), da.clone(), dc.clone())
+                self.conv_wgrad(hin, dc, G[pre + "0.weight"], G[pre + "0.bias"], B, hh, ww, cin, cout, 3, fp32=True, bias_grad=False)  # BN in training mode
+                if idx > 0:
+                    dh = self.new(Rr, cin)
+                    self.conv_dgrad(dc, P[pre + "0.weight"], dh, B, hh, ww, cin, cout, 3, fp32=True)
+                if idx in (8, 4):
+                    self._w_flush()
         on_stage("head")
         on_stage("infogen")
 

@@ -114,6 +114,8 @@ class SRTrainer:
         # input, three rotations, (1 - TRI_SSIM) * 10; `--training_stablize` masks the per-sample image loss (:241-242)
         self.tsc, self.tssim_rotation_degree, self.training_stablize = tsc, tssim_rotation_degree, training_stablize
         self.tssim = None                                     # device scalar: TRI_SSIM of the last step
+        import os
+        self.tsc_batched = os.environ.get("TATT_TSC_BATCH", "1") != "0"   # both SR passes of a TSC step as one 2B-row batch (0: one after the other)
         named = list(model.named_parameters())
         dev = named[0][1].device
         if dev.type != "cuda":
@@ -164,11 +166,24 @@ class SRTrainer:
         L, B = self.L, lr_img.shape[0]
         self.flat_g.zero_()
         L.seed_bump(self.seed_dev)
-        sr, ctx = self.eng.forward(lr_img, tp, True, 0, tp_ready=tp_ready)
+        batched = self.tsc and self.tsc_batched and self.eng.dec_fused
+        if self.tsc:
+            arc = arc.to(device=lr_img.device, dtype=torch.float32)
+        if batched:
+            # The two SR passes of the step (interfaces/super_resolution_eng.py:233 on the LR image, :259 on the rotated LR image: the
+            # second reads the rotated INPUT, not the first one's output) as ONE batch of 2B rows through every launch; BatchNorm
+            # statistics, dropout masks (seeds 0 / 1), the STN head and the text branch stay per pass (Engine.forward(x2=...)).
+            d_lr = torch.empty_like(lr_img)
+            L.rotate_fwd(lr_img, arc, d_lr, B, lr_img.shape[1], lr_img.shape[2], lr_img.shape[3])
+            sr_all, ctx = self.eng.forward(lr_img, tp, True, 0, tp_ready=tp_ready, x2=d_lr, seed2=1)
+            sr, sr2 = sr_all[:B], sr_all[B:]
+        else:
+            sr, ctx = self.eng.forward(lr_img, tp, True, 0, tp_ready=tp_ready)
         C, H, W = sr.shape[1:]
         per = torch.empty(B, device=sr.device)
         L.image_loss_fwd(sr, hr_img, per, B, C, H, W, self.loss_weight[0], self.loss_weight[1])
-        dsr = torch.empty_like(sr)
+        dsr_all = torch.empty(2 * B, C, H, W, device=sr.device) if batched else None
+        dsr = dsr_all[:B] if batched else torch.empty_like(sr)
         if self.training_stablize:
             mask = self.loss_stablizing_mask(per)
             per = per * mask
@@ -177,20 +192,25 @@ class SRTrainer:
             L.image_loss_bwd(sr, hr_img, None, 100.0 / B, dsr, B, C, H, W, self.loss_weight[0], self.loss_weight[1])
         if self.tsc:
             # D(F(Y)), F(D(Y)), D(X): the rotated SR output, the SR of the rotated input, the rotated HR image
-            arc = arc.to(device=sr.device, dtype=torch.float32)
-            d_sr, d_hr, d_lr = torch.empty_like(sr), torch.empty_like(hr_img), torch.empty_like(lr_img)
+            d_sr, d_hr = torch.empty_like(sr), torch.empty_like(hr_img)
             L.rotate_fwd(sr, arc, d_sr, B, C, H, W)
             L.rotate_fwd(hr_img, arc, d_hr, B, C, H, W)
-            L.rotate_fwd(lr_img, arc, d_lr, B, lr_img.shape[1], lr_img.shape[2], lr_img.shape[3])
-            # seed 1: its own dropout masks; packed weights and the recurrent positional encoding (a function of the weights alone)
-            # are those of the first pass, whose backward pass below also runs the one BPTT chain for both
-            sr2, ctx2 = self.eng.forward(d_lr, tp, True, 1, wpack=ctx["wpack"], rpe_from=ctx)
+            if not batched:
+                d_lr = torch.empty_like(lr_img)
+                L.rotate_fwd(lr_img, arc, d_lr, B, lr_img.shape[1], lr_img.shape[2], lr_img.shape[3])
+                # seed 1: its own dropout masks; packed weights and the recurrent positional encoding (a function of the weights alone)
+                # are those of the first pass, whose backward pass below also runs the one BPTT chain for both
+                sr2, ctx2 = self.eng.forward(d_lr, tp, True, 1, wpack=ctx["wpack"], rpe_from=ctx)
             self.tssim = torch.empty(1, device=sr.device)
             L.tri_ssim_fwd(d_sr, sr2, d_hr, self.tssim, B, C, H, W, self.ws_ssim(B * C))
-            g_rot, g_sr2 = torch.empty_like(sr), torch.empty_like(sr)
+            g_rot = torch.empty_like(sr)
+            g_sr2 = dsr_all[B:] if batched else torch.empty_like(sr)
             L.tri_ssim_bwd(d_sr, sr2, d_hr, -10.0, g_rot, g_sr2, 0, B, C, H, W)      # loss_tssim = (1 - mean) * 10
             L.rotate_bwd(arc, g_rot, dsr, B, C, H, W)                                # += onto the image-loss gradient
-            self.eng.backward(ctx2, g_sr2, self.G)
+            if not batched:
+                self.eng.backward(ctx2, g_sr2, self.G)
+        if batched:
+            dsr = dsr_all
         works = []
         cut = on_stage
 

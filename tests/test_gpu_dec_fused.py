@@ -85,7 +85,7 @@ def test_dec_fused_fwd_bwd_vs_fp64(B, Lq):
     tg, q_, nw_, nb_ = cu(tgt), cu(qp), cu(nw), cu(nb)
     sites = (U32 * 8)(*range(8))
     lib.dec_fwd(tg, q_, packed, (VP * 2)(*[t.data_ptr() for t in tabs]), (VP * 16)(*[t.data_ptr() for ps in params for t in ps]), nw_, nb_,
-                (VP * 14)(*[t.data_ptr() for sv in saved for t in sv]), tp, B, Lq, sites, 0, 1.0, None)
+                (VP * 14)(*[t.data_ptr() for sv in saved for t in sv]), tp, B, Lq, 1, sites, 0, 1.0, None)
     close(tp, tp_ref, 2e-5, "tp_map")
 
     dtp = cu(wout)
@@ -96,7 +96,7 @@ def test_dec_fused_fwd_bwd_vs_fp64(B, Lq):
         kvpart, lnpart = new(lib.dec_bwd_kvpart_floats(B, Lq)), new(lib.dec_bwd_lnpart_floats(B, Lq))
         lib.dec_bwd(li, None if li == 1 else dtgt1, dtp, packed, tabs[li], (VP * 8)(*[t.data_ptr() for t in params[li]]), nw_,
                     (VP * 7)(*[t.data_ptr() for t in saved[li]]), dtgt1 if li == 1 else dtgt0, 0 if li == 1 else 1, dqp, 0 if li == 1 else 1,
-                    (VP * 4)(*[t.data_ptr() for t in dY]), kvpart, lnpart, B, Lq, (U32 * 4)(*range(4 * li, 4 * li + 4)), 0, 1.0, None)
+                    (VP * 4)(*[t.data_ptr() for t in dY]), kvpart, lnpart, B, Lq, 1, (U32 * 4)(*range(4 * li, 4 * li + 4)), 0, 1.0, None)
         gl = [torch.zeros(64, device="cuda") for _ in range(4)]
         lib.dec_ln_final(lnpart, B, Lq, (VP * 6)(*[t.data_ptr() for t in gl + gnorm]))
         dK, dV = new(Rt, 64), new(Rt, 64)

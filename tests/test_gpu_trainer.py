@@ -103,6 +103,41 @@ def test_tsc_step_matches_oracle_step():
         assert np.mean(np.sign(d_gpu) == np.sign(d_ref)) > 0.99, k
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_tsc_batched_passes_equal_sequential_passes(p_drop):
+    """The two SR passes of a TSC step as one 2B-row batch (Engine.forward(x2=...): per-pass BatchNorm statistics, dropout seeds, STN head
+    and text branch) against the same step with one pass after the other (rpe_from): loss terms, every gradient, BatchNorm running
+    statistics after their two updates, num_batches_tracked == 2."""
+    from tatt_amd.trainer import SRTrainer
+    B = 8
+    state = make_state(37, seed=9)
+    hr, lr, tp = procgen.make_inputs(B, 37, seed=10)
+    arc = torch.linspace(-0.17, 0.17, B)
+    res = []
+    for batched in (True, False):
+        m = build(copy.deepcopy(state))
+        m.dropout_p = p_drop
+        tr = SRTrainer(m, use_graph=False, tsc=True)
+        tr.tsc_batched = batched
+        per = tr.step(lr.cuda(), hr.cuda(), tp.cuda(), arc=arc)
+        torch.cuda.synchronize()
+        sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        res.append((per.cpu(), float(tr.tssim), tr.flat_g.cpu().clone(), float(tr.state[0]), sd, {n: g.cpu().clone() for n, g in tr.G.items()}))
+    (per_a, ts_a, g_a, n_a, sd_a, G_a), (per_b, ts_b, g_b, n_b, sd_b, G_b) = res
+    assert rel_l2(per_a.numpy(), per_b.numpy()) < 1e-6 and abs(ts_a - ts_b) < 1e-6
+    assert abs(n_a - n_b) < 1e-5 * n_b
+    assert int(sd_a["block3.bn1.num_batches_tracked"]) == 2 and int(sd_a["stn_head.stn_convnet.4.1.num_batches_tracked"]) == 2
+    for k in sd_a:
+        if "running_" in k:
+            assert rel_l2(sd_a[k].double().numpy(), sd_b[k].double().numpy()) < 1e-6, k
+    from tatt_amd.engine import unused_param
+    for n in G_a:
+        if unused_param(n) or n == "stn_head.stn_fc1.0.bias":
+            continue
+        r = rel_l2(G_a[n].numpy(), G_b[n].numpy())
+        assert r < 5e-5, (n, r)
+
+
 def test_step_normalises_input_layout_and_dtype():
     """step() accepts what a data loader may hand over -- a sliced (non-contiguous) LR batch, a double HR batch, a non-contiguous
     prior view -- and computes the same step as with plain contiguous fp32 tensors (TSC on: the rotation and the second SR pass read

@@ -31,7 +31,7 @@ sites = (U32 * 8)(*range(1, 9))
 
 def fwd():
     L.dec_fwd(tgt, qp, packed, (VP * 2)(*[t.data_ptr() for t in tabs]), (VP * 16)(*[t.data_ptr() for ps in params for t in ps]), nw, nb,
-              (VP * 14)(*[t.data_ptr() for sv in saved for t in sv]), tp, B, Lq, sites, thresh, scale, None)
+              (VP * 14)(*[t.data_ptr() for sv in saved for t in sv]), tp, B, Lq, 1, sites, thresh, scale, None)
 
 
 dtp, dtgt1, dtgt0, dqp = new(R0, 64), torch.empty(R0, 64, device="cuda"), torch.zeros(R0, 64, device="cuda"), torch.empty(R0, 64, device="cuda")
@@ -43,7 +43,7 @@ lnpart = torch.empty(L.dec_bwd_lnpart_floats(B, Lq), device="cuda")
 def bwd(li):
     L.dec_bwd(li, None if li == 1 else dtgt1, dtp, packed, tabs[li], (VP * 8)(*[t.data_ptr() for t in params[li]]), nw,
               (VP * 7)(*[t.data_ptr() for t in saved[li]]), dtgt1 if li == 1 else dtgt0, 0 if li == 1 else 1, dqp, 0 if li == 1 else 1,
-              (VP * 4)(*[t.data_ptr() for t in dY]), kvpart, lnpart, B, Lq, (U32 * 4)(*range(1 + 4 * li, 5 + 4 * li)), thresh, scale, None)
+              (VP * 4)(*[t.data_ptr() for t in dY]), kvpart, lnpart, B, Lq, 1, (U32 * 4)(*range(1 + 4 * li, 5 + 4 * li)), thresh, scale, None)
 
 
 def timeit(fn, n=20):
