@@ -173,9 +173,10 @@ def self_launch(n, argv):
     cmd = launch_command(n, argv, int(os.environ.get("MASTER_PORT", 0)) or free_port())
     print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    for line in proc.stdout:
-        sys.stdout.write(line)
-        sys.stdout.flush()
+    for line in proc.stdout:                 # the child ranks' stdout: rank 0's JSON line (anything else a library printed goes to stderr)
+        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+        out.write(line)
+        out.flush()
     rc = proc.wait()
     if rc != 0:
         print(f"bench.py: the {n}-rank child run failed with exit code {rc}", file=sys.stderr, flush=True)
@@ -215,6 +216,11 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} (local rank {local}) has no GPU: this node shows {ndev} device(s), the run needs {world} "
                          "(one process per GPU)")
     torch.cuda.set_device(local)
+    # ONE JSON line on stdout: libraries that print to fd 1 (RCCL's version banner at communicator set-up does) get stderr instead;
+    # the line itself goes through a private copy of the original stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
@@ -314,7 +320,7 @@ def main():
             out["roofline"].update(in_step_launch_us() or {})
         if world == 1 and not a.no_cpu_baseline and not a.tsc and not a.full:
             out["cpu_baseline"] = cpu_baseline(state_cpu, a.batch, a.K)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
