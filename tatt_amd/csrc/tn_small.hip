@@ -45,7 +45,8 @@ __device__ __forceinline__ void tn_small_body(const float* __restrict__ dY, long
 
   // Two register sets of U k-pairs each: the loads of the next set are issued before the MFMAs of the current one, so the
   // HBM latency and the matrix work (0.8 GFLOP for a [96,64] output, as long as the 42 MB stream itself) overlap inside a
-  // wave instead of adding up.  Straight-line, two sets per trip.  (A ring of four sets, loads three sets ahead, measured no
+  // wave instead of adding up.  (Knock-outs on the six-problem GruBlock group, 50.9 us: without the MFMAs 40.9 us, without the
+  // loads 45.0 us -- the launch runs at the pace of its matrix instructions at the clock the chip sustains.)  Straight-line, two sets per trip.  (A ring of four sets, loads three sets ahead, measured no
   // faster: the kernel is not latency-bound once the loop is branch-free.)
   constexpr int U = 4;
   float av0[U][MT], bv0[U][NT], av1[U][MT], bv1[U][NT];
@@ -166,16 +167,22 @@ struct TnGroup {
   float* db[TN_GROUP];
   long lddy[TN_GROUP], ldx[TN_GROUP], lddw[TN_GROUP], slab_off[TN_GROUP];
   int M[TN_GROUP], N[TN_GROUP], R[TN_GROUP], rpb[TN_GROUP], nblk[TN_GROUP];
+  int first[TN_GROUP + 1];  // problem p owns blocks [first[p], first[p + 1]) of the one-dimensional grid
 };
 
 __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_group_kernel(TnGroup g, float* __restrict__ slabs) {
   __shared__ float red[(TN_WAVES / 2) * (3 * 32 * 2 * 32 + 3 * 32)];
-  const int p = blockIdx.y;
-  if ((int)blockIdx.x >= g.nblk[p]) return;
+  // The grid is exactly the blocks that have work, problem after problem: at most one per CU, and the hardware's round-robin
+  // of consecutive blocks over the eight XCDs then gives every XCD at most 32 of them.  (A [nb_max, nprob] grid whose surplus
+  // blocks exit at once put up to 39 working blocks on one XCD: two rounds, 89 us instead of 56.)
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < TN_GROUP; ++q) p += (int)blockIdx.x >= g.first[q] ? 1 : 0;   // first[] is non-decreasing, padded with the total
+  const int blk = (int)blockIdx.x - g.first[p];
   // block-uniform dispatch on the problem's tile shape (a per-MFMA "skip this tile" branch inside one shape split the loop into
   // a basic block per MFMA: nothing overlapped)
   const int mt = (g.M[p] + 31) >> 5, nt = (g.N[p] + 31) >> 5;
-#define TN_BODY(a, b) tn_small_body<a, b>(g.dY[p], g.lddy[p], g.dY2[p], g.lddy2[p], g.msplit[p], g.X[p], g.ldx[p], g.M[p], g.N[p], g.R[p], g.rpb[p], slabs + g.slab_off[p], blockIdx.x, red)
+#define TN_BODY(a, b) tn_small_body<a, b>(g.dY[p], g.lddy[p], g.dY2[p], g.lddy2[p], g.msplit[p], g.X[p], g.ldx[p], g.M[p], g.N[p], g.R[p], g.rpb[p], slabs + g.slab_off[p], blk, red)
   if (nt == 1) {
     if (mt == 1) TN_BODY(1, 1);
     else if (mt == 2) TN_BODY(2, 1);
@@ -262,15 +269,19 @@ int tatt_tn_small_group(int nprob, const float* const* dY, const long* lddy, con
                  "tatt_tn_small_group: need 1..%d problems and non-null arrays", TN_GROUP);
   TnGroup g;
   memset(&g, 0, sizeof(g));
-  int nb = TN_MAXBLK / nprob;  // blocks per problem: one 8-wave block per CU in total
-  if (nb < 1) nb = 1;
+  // one 8-wave block per CU in total, shared out in proportion to each problem's matrix work per row (its count of 32x32
+  // output tiles): equal shares left the blocks of a [96,32] problem idle while those of a [96,64] one ran twice as long
+  int wsum = 0;
+  for (int p = 0; p < nprob; ++p) wsum += ((M[p] + 31) / 32) * ((N[p] + 31) / 32);
   long off = 0;
-  int per_max = 0, nb_max = 0;
+  int per_max = 0;
   for (int p = 0; p < nprob; ++p) {
     TATT_CHECK_ARG(M[p] > 0 && N[p] > 0 && R[p] > 0 && M[p] <= 96 && N[p] <= 64 && dY[p] && X[p] && dW[p],
                    "tatt_tn_small_group: problem %d: need 0 < M <= 96, 0 < N <= 64, R > 0", p);
     TATT_CHECK_ARG(lddy[p] > 0 && ldx[p] > 0 && ((long)R[p] + 1) * lddy[p] * 4 < (1L << 31) && ((long)R[p] + 1) * ldx[p] * 4 < (1L << 31),
                    "tatt_tn_small_group: problem %d: operands must span less than 2 GiB (32-bit buffer offsets)", p);
+    int nb = wsum > 0 ? TN_MAXBLK * (((M[p] + 31) / 32) * ((N[p] + 31) / 32)) / wsum : 1;
+    if (nb < 1) nb = 1;
     int nblk = (R[p] + 255) / 256;
     if (nblk > nb) nblk = nb;
     const int rpb = ((R[p] + nblk - 1) / nblk + 15) / 16 * 16;
@@ -285,12 +296,13 @@ int tatt_tn_small_group(int nprob, const float* const* dY, const long* lddy, con
     g.lddy[p] = lddy[p]; g.ldx[p] = ldx[p]; g.lddw[p] = lddw[p];
     g.M[p] = M[p]; g.N[p] = N[p]; g.R[p] = R[p]; g.rpb[p] = rpb; g.nblk[p] = nblk;
     g.slab_off[p] = off;
+    g.first[p + 1] = g.first[p] + nblk;
     const int per = M[p] * N[p] + M[p];
     off += (long)nblk * per;
     if (per > per_max) per_max = per;
-    if (nblk > nb_max) nb_max = nblk;
   }
-  hipLaunchKernelGGL(tn_small_group_kernel, dim3(nb_max, nprob), dim3(TN_WAVES * 64), 0, st, g, workspace);
+  for (int p = nprob; p < TN_GROUP; ++p) g.first[p + 1] = g.first[nprob];
+  hipLaunchKernelGGL(tn_small_group_kernel, dim3(g.first[nprob]), dim3(TN_WAVES * 64), 0, st, g, workspace);
   TATT_LAUNCH_CHECK("tn_small_group_kernel");
   hipLaunchKernelGGL(tn_small_group_reduce, dim3(cdiv(per_max, 16), nprob), dim3(256), 0, st, g, workspace);
   TATT_LAUNCH_CHECK("tn_small_group_reduce");
