@@ -1298,6 +1298,125 @@ int launch(const GemmArgs& a, int batch, hipStream_t st) {
   return TATT_OK;
 }
 
+// ---- weight gradient of the SRB convolutions (3x3, 64 -> 64: T*Cin = 576 = 3 x 192, Cout <= 64), fp32 MFMA ---------------------
+// dW^T[(tap,ci)][co] = sum_pixels X[pixel + shift(tap)][ci] * dY[pixel][co]: both operands are pixel-major, so both LDS images are
+// row-contiguous ([k][m], [k][n]) and the generic tile above pays two ds_read_b32 per MFMA (knock-out: 57.7 us with them, 47.4 us
+// without) and pads M = 576 to five 128-row tiles.  Here the tile is 192 x 64 x 32 with twelve waves = 3 (M) x 2 (N) x 2 (halves of
+// the 32-pixel k tile): a wave owns 64 rows as two interleaved 32-row sub-tiles (rows 2i and 2i + 1), so one ds_read_b64 of A and
+// one ds_read_b32 of B feed two MFMAs, M needs no padding, and the two k halves are added through LDS once, in the epilogue.
+// Slab format, split-K and the slab sum are those of the generic launch.
+constexpr int WG_BM = 192, WG_THR = 768, WG_BUF = (WG_BM + BN) * BK;
+__global__ __launch_bounds__(WG_THR, 6) void wgrad192_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * WG_BUF];  // 64 KB: two workgroups (24 waves) per CU
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave % 3, wn = (wave / 3) & 1, kh = wave / 6;
+  const int m0 = blockIdx.x * WG_BM;
+  const int zs = blockIdx.z;
+  const int kbeg = zs * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+  const int ntiles = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(a.A), rsrcB = make_rsrc(a.B);
+  // A loader: thread -> four consecutive m = (tap, ci..ci+3) at pixels a_k and a_k + 16 of the tile
+  const int a_m4 = tid % 48, a_k = tid / 48;
+  int fa_vo[2], fa_x[2], tdy;
+  {
+    const int m = m0 + a_m4 * 4;
+    const int tap = m / a.g.Cin, ci = m - tap * a.g.Cin;
+    tdy = tap / a.g.KW - a.g.padH;
+    const int tdx = tap % a.g.KW - a.g.padW;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fa_x[j] = a_k + 16 * j + tdx;
+      fa_vo[j] = (((tdy * a.g.W + tdx) + a_k + 16 * j) * a.g.ldx + ci) * 4;
+    }
+  }
+  // B loader (waves 0..7): thread -> four consecutive co of pixel b_k
+  const int b_n4 = tid & 15, b_k = tid >> 4;
+  const bool b_thr = wave < 8;
+  const int fb_vo = (b_thr && b_n4 * 4 < a.N) ? (int)(((long)b_k * a.sbk + b_n4 * 4) * 4) : BUF_OOB;
+  int t_k0 = kbeg, t_y, t_x0;
+  {
+    const int rem = kbeg % (a.g.H * a.g.W);
+    t_y = rem / a.g.W;
+    t_x0 = rem - t_y * a.g.W;
+  }
+  float4 ra0[2], rb0, ra1[2], rb1;
+  auto load_tiles = [&](float4 (&ra)[2], float4& rb) {  // W % 32 == 0: the tile's 32 pixels share one image row
+    const int lim = kend - t_k0;
+    const int spix = t_k0 * a.g.ldx * 4;
+    const bool yok = (unsigned)(t_y + tdy) < (unsigned)a.g.H;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = yok && a_k + 16 * j < lim && (unsigned)(t_x0 + fa_x[j]) < (unsigned)a.g.W;
+      ra[j] = bload4s(rsrcA, ok ? fa_vo[j] + spix : BUF_OOB, 0);
+    }
+    rb = bload4s(rsrcB, b_k < lim ? fb_vo : BUF_OOB, t_k0 * (int)a.sbk * 4);
+    t_k0 += BK;
+    t_x0 += BK;
+    if (t_x0 >= a.g.W) {
+      t_x0 = 0;
+      if (++t_y == a.g.H) t_y = 0;
+    }
+  };
+  auto store_tiles = [&](int buf, const float4 (&ra)[2], const float4& rb) {
+    float* As = lds + buf * WG_BUF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(As + (a_k + 16 * j) * WG_BM + a_m4 * 4) = ra[j];
+    if (b_thr) *reinterpret_cast<float4*>(As + WG_BM * BK + b_k * BN + b_n4 * 4) = rb;
+  };
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+  auto compute = [&](int cur) {
+    const float* As = lds + cur * WG_BUF + (kh * 16 + lh) * WG_BM + wm * 64 + 2 * li;
+    const float* Bs = lds + cur * WG_BUF + WG_BM * BK + (kh * 16 + lh) * BN + wn * 32 + li;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const float2 av = *reinterpret_cast<const float2*>(As + 2 * p * WG_BM);
+      const float bv = Bs[2 * p * BN];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv, acc1, 0, 0, 0);
+    }
+  };
+  load_tiles(ra0, rb0);
+  load_tiles(ra1, rb1);
+  store_tiles(0, ra0, rb0);
+  load_tiles(ra0, rb0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; t += 2) {  // two tiles per trip, straight-line (see gemm_body); tiles past the end are all zeros
+    store_tiles(1, ra1, rb1);
+    load_tiles(ra1, rb1);
+    compute(0);
+    __syncthreads();
+    store_tiles(0, ra0, rb0);
+    load_tiles(ra0, rb0);
+    compute(1);
+    __syncthreads();
+  }
+  // ---- epilogue: the k-half-1 waves park their accumulators in LDS, the k-half-0 waves add them and write the slab ----
+  float* red = lds;  // [6 waves][32 regs][64 lanes] = 48 KB
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      red[((wave - 6) * 32 + r) * 64 + lane] = acc0[r];
+      red[((wave - 6) * 32 + 16 + r) * 64 + lane] = acc1[r];
+    }
+  }
+  __syncthreads();
+  if (kh == 1) return;
+  const int n = wn * 32 + li;
+  if (n >= a.N) return;
+  float* Cp = a.C + zs * a.sCz;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh);
+    Cp[(long)m * a.ldc + n] = acc0[r] + red[(wave * 32 + r) * 64 + lane];
+    Cp[(long)(m + 1) * a.ldc + n] = acc1[r] + red[(wave * 32 + 16 + r) * 64 + lane];
+  }
+}
+const int g_wgrad192 = [] { const char* e = getenv("TATT_WGRAD192"); return (e && e[0] == '0') ? 0 : 1; }();  // =0: the generic tile (A/B runs)
+
 // launches with a BatchNorm epilogue (EPI 1 / 2, see GemmArgs): FAST loaders only, one K pass, whole tile rows
 template <int AOP, int BOP, int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t st) {
@@ -1649,7 +1768,10 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
     a.ldc = a.N;
     a.sCz = (long)a.M * a.N;
     perm = 2;
-    if (int rc = launch<OP_IM2COL_M, OP_ROWCONTIG>(a, 1, st)) return rc;
+    if (g_wgrad192 && a.bf16 == 0 && a.M % WG_BM == 0 && fast_ok<OP_IM2COL_M, OP_ROWCONTIG>(a)) {
+      hipLaunchKernelGGL(wgrad192_kernel, dim3(a.M / WG_BM, 1, splitk), dim3(WG_THR), 0, st, a);
+      TATT_LAUNCH_CHECK("wgrad192_kernel");
+    } else if (int rc = launch<OP_IM2COL_M, OP_ROWCONTIG>(a, 1, st)) return rc;
   } else {
     // the kernel treats splitk>1 as "write raw slabs"; with splitk==1 it applies bias/accumulate (none set): same result.
     if (int rc = launch<OP_ROWCONTIG, OP_IM2COL_N>(a, 1, st)) return rc;

@@ -25,6 +25,8 @@ STN_STAGES = [(0, 4, 32, (2, 2)), (2, 32, 64, (2, 2)), (4, 64, 128, (2, 2)), (6,
 RPE_CHAIN = os.environ.get("TATT_RPE_CHAIN", "1") != "0"   # 0: one launch per step of the RPE recurrence (A/B runs)
 DEC_FUSED = os.environ.get("TATT_DEC_FUSED", "1") != "0"   # 0: the decoder as one launch per projection / attention / LayerNorm (A/B runs)
 WS_FLOATS = 48 * 1024 * 1024
+WGRAD192_WGS = int(os.environ.get("TATT_WGRAD192_WGS", "255"))
+WGRAD_WGS = int(os.environ.get("TATT_WGRAD_WGS", "480"))   # workgroups of a convolution weight-gradient launch (split-K factor = this / tiles)
 NODROP = (0, 0, 1.0, None)
 
 
@@ -353,7 +355,10 @@ class Engine:
             tiles = -(-(T * Cin) // 128)
         else:                                                  # M = Cout, N = T*Cin
             tiles = -(-Cout // 128) * -(-(T * Cin) // 64)
-        sk = max(1, min((B * H * Wd) // 256, -(-768 // tiles)))        # ~3 workgroups per CU (swept 256..1536: flat within 1 %)
+        sk = -(-WGRAD_WGS // tiles)
+        if WGRAD192_WGS and 16 < Cout <= 64 and (T * Cin) % 192 == 0 and Wd % 32 == 0 and (self.px if fp32 else self.pf) == 0:
+            sk = WGRAD192_WGS // (T * Cin // 192)              # wgrad192_kernel (fp32 MFMA): one twelve-wave workgroup per CU, never 257
+        sk = max(1, min((B * H * Wd) // 256, sk))        # 3x3 64->64: 96 slabs; in the step 7.10 ms against 7.20 with 154 (standalone 57.7 / 61.0 us, and a shorter slab sum)
         while sk > 1 and Cout * T * Cin * sk > WS_FLOATS:
             sk //= 2
         fl = 1 | (self.px if fp32 else self.pf)

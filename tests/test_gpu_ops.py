@@ -166,6 +166,24 @@ def test_conv3x3_wgrad_borders_and_slices(B, H, W, sk):
     close(dW, w.grad, what="overwrite")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,sk", [(2, 4, 32, 64, 48, 3, 3), (1, 2, 96, 128, 20, 3, 5), (3, 3, 32, 192, 64, 1, 2), (1, 16, 64, 64, 64, 3, 85),
+                                                 (2, 5, 64, 64, 36, 3, 1)])
+def test_conv_wgrad_192_row_tile(B, H, W, Cin, Cout, k, sk):
+    """Shapes that take wgrad192_kernel (fp32, T*Cin a multiple of 192, W a multiple of 32, 16 < Cout <= 64): partial N tile,
+    several M tiles, 1x1, odd tile counts per slab, slabs past the end of the pixels."""
+    T = k * k
+    assert (T * Cin) % 192 == 0 and W % 32 == 0
+    x, dy = rnd(B, Cin, H, W), rnd(B, Cout, H, W, seed=3)
+    w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, padding=k // 2).backward(dy.double())
+    xn, dyn = cu(x.permute(0, 2, 3, 1)), cu(dy.permute(0, 2, 3, 1))
+    dW = torch.full((Cout, Cin, k, k), 1.0, device="cuda")
+    L().conv_wgrad(xn, dyn, dW, B, H, W, Cin, Cout, k, k, Cin, Cout, sk, ws(), 1)
+    close(dW, w.grad + 1.0, what="accumulate")
+    L().conv_wgrad(xn, dyn, dW, B, H, W, Cin, Cout, k, k, Cin, Cout, sk, ws(), 0)
+    close(dW, w.grad, what="overwrite")
+
+
 @pytest.mark.parametrize("B,H,W,Cbig,Csmall,k", [(2, 32, 128, 64, 4, 9), (3, 16, 64, 64, 4, 9), (2, 7, 70, 32, 4, 9), (1, 3, 5, 16, 4, 9), (2, 8, 8, 32, 8, 3), (1, 5, 7, 64, 16, 3)])
 def test_conv_skinny_fwd_and_dgrad(B, H, W, Cbig, Csmall, k):
     """Skinny-Cout path: forward Cbig->Csmall, and the dgrad of a Csmall->Cbig conv (model/tsrn.py:625, :598)."""
