@@ -138,6 +138,9 @@ int tatt_ln_bwd(const float* v, const float* dy, float dyscale, const float* gam
 
 /* ---- BiGRU(64 -> 2x32) recurrence of GruBlock (model/tsrn.py:1080,:1088), persistent half-wave per sequence - */
 int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* out, float* save, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride, hipStream_t stream);
+/* the same recurrence, and out2 [P,64] = res [P,64] + out: the sum of SRB input and first GruBlock that the second GruBlock reads
+ * (model/tsrn.py:901 "x + residual") written by the recurrence itself instead of a 16.8 MB element-wise launch */
+int tatt_gru32_fwd_res(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* out, float* save, const float* res, float* out2, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride, hipStream_t stream);
 /* dgi [P,192] = gradient of the input projections (dr, dz, dn per direction); dghn [P,64] (dir*32 + j) = dn * r, the one gate where
  * the gradient of W_hh h + b_hh differs from dgi; hprev [P,64] = the state each step started from. */
 int tatt_gru32_bwd(const float* dout, const float* out, const float* save, const float* whh_f, const float* whh_b, float* dgi, float* dghn, float* hprev, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride, hipStream_t stream);

@@ -24,10 +24,14 @@ __device__ __forceinline__ long seq_base(const SeqMap& m, int s) {
 }
 
 // gi [P,192] (dir*96 + gate*32 + j); whh/bhh: per-direction pointers; out [P,64]; save [P,2,4,32] or null
+// RES: also out2 [P,64] = res [P,64] + out (the "x + residual" that feeds the second GruBlock of an SRB, model/tsrn.py:901): the
+// residual rides the same three-set prefetch as the input projections, so the 16.8 MB add never is a launch of its own
+template <bool RES>
 __global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, const float* __restrict__ whh_f,
                                                  const float* __restrict__ whh_b, const float* __restrict__ bhh_f,
                                                  const float* __restrict__ bhh_b, float* __restrict__ out,
-                                                 float* __restrict__ save, int nseq, SeqMap sm) {
+                                                 float* __restrict__ save, int nseq, SeqMap sm, const float* __restrict__ res,
+                                                 float* __restrict__ out2) {
   __shared__ __attribute__((aligned(16))) float hbuf[8][HID];
   const int tid = threadIdx.x, j = tid & 31, slot = tid >> 5;
   int wi = blockIdx.x * 8 + slot;
@@ -55,18 +59,22 @@ __global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, c
   // the loads; see gru32_bwd for why one set ahead is not enough).
   constexpr int PF = 4;
   const float* gcol = gi + dir * 96 + j;
+  const float* ocol = RES ? res + dir * HID + j : nullptr;
   float rA[PF], zA[PF], nA[PF], rB[PF], zB[PF], nB[PF], rC[PF], zC[PF], nC[PF];
-  auto fetch = [&](int t0, float (&fr)[PF], float (&fz)[PF], float (&fn)[PF]) {
+  float oA[PF], oB[PF], oC[PF];
+  auto fetch = [&](int t0, float (&fr)[PF], float (&fz)[PF], float (&fn)[PF], float (&fo)[PF]) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int tc = min(t0 + u, T - 1);
-      const float* q = gcol + (base + (long)(dir ? T - 1 - tc : tc) * sm.tstride) * 192;
+      const long px = base + (long)(dir ? T - 1 - tc : tc) * sm.tstride;
+      const float* q = gcol + px * 192;
       fr[u] = q[0];
       fz[u] = q[HID];
       fn[u] = q[2 * HID];
+      if constexpr (RES) fo[u] = ocol[px * 64];
     }
   };
-  auto steps = [&](int t0, const float (&c_r)[PF], const float (&c_z)[PF], const float (&c_n)[PF]) {
+  auto steps = [&](int t0, const float (&c_r)[PF], const float (&c_z)[PF], const float (&c_n)[PF], const float (&c_o)[PF]) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       if (t0 + u >= T) break;
@@ -92,6 +100,7 @@ __global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, c
       hbuf[slot][j] = h;
       if (active) {
         out[pix * 64 + dir * HID + j] = h;
+        if constexpr (RES) out2[pix * 64 + dir * HID + j] = h + c_o[u];
         if (save) {
           float* sp = save + (pix * 2 + dir) * 4 * HID;
           sp[j] = r;
@@ -103,15 +112,15 @@ __global__ __launch_bounds__(256) void gru32_fwd(const float* __restrict__ gi, c
       pix += pstep;
     }
   };
-  fetch(0, rA, zA, nA);
-  fetch(PF, rB, zB, nB);
+  fetch(0, rA, zA, nA, oA);
+  fetch(PF, rB, zB, nB, oB);
   for (int t0 = 0; t0 < T; t0 += 3 * PF) {
-    fetch(t0 + 2 * PF, rC, zC, nC);
-    steps(t0, rA, zA, nA);
-    fetch(t0 + 3 * PF, rA, zA, nA);
-    steps(t0 + PF, rB, zB, nB);
-    fetch(t0 + 4 * PF, rB, zB, nB);
-    steps(t0 + 2 * PF, rC, zC, nC);
+    fetch(t0 + 2 * PF, rC, zC, nC, oC);
+    steps(t0, rA, zA, nA, oA);
+    fetch(t0 + 3 * PF, rA, zA, nA, oA);
+    steps(t0 + PF, rB, zB, nB, oB);
+    fetch(t0 + 4 * PF, rB, zB, nB, oB);
+    steps(t0 + 2 * PF, rC, zC, nC, oC);
   }
 }
 
@@ -841,8 +850,19 @@ int tatt_gru32_fwd(const float* gi, const float* whh_f, const float* whh_b, cons
                    float* save, int nseq, int T, int inner, long outer_stride, long inner_stride, long tstride, hipStream_t st) {
   TATT_CHECK_ARG(nseq > 0 && T > 0 && inner > 0, "tatt_gru32_fwd: bad dims");
   SeqMap sm{inner, outer_stride, inner_stride, tstride, T};
-  hipLaunchKernelGGL(gru32_fwd, dim3(cdiv(nseq * 2, 8)), dim3(256), 0, st, gi, whh_f, whh_b, bhh_f, bhh_b, out, save, nseq, sm);
+  hipLaunchKernelGGL(gru32_fwd<false>, dim3(cdiv(nseq * 2, 8)), dim3(256), 0, st, gi, whh_f, whh_b, bhh_f, bhh_b, out, save, nseq, sm,
+                     (const float*)nullptr, (float*)nullptr);
   TATT_LAUNCH_CHECK("gru32_fwd");
+  return TATT_OK;
+}
+
+int tatt_gru32_fwd_res(const float* gi, const float* whh_f, const float* whh_b, const float* bhh_f, const float* bhh_b, float* out,
+                       float* save, const float* res, float* out2, int nseq, int T, int inner, long outer_stride, long inner_stride,
+                       long tstride, hipStream_t st) {
+  TATT_CHECK_ARG(nseq > 0 && T > 0 && inner > 0 && res && out2 && out2 != out, "tatt_gru32_fwd_res: bad dims / null residual or second output");
+  SeqMap sm{inner, outer_stride, inner_stride, tstride, T};
+  hipLaunchKernelGGL(gru32_fwd<true>, dim3(cdiv(nseq * 2, 8)), dim3(256), 0, st, gi, whh_f, whh_b, bhh_f, bhh_b, out, save, nseq, sm, res, out2);
+  TATT_LAUNCH_CHECK("gru32_fwd_res");
   return TATT_OK;
 }
 

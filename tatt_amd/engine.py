@@ -25,6 +25,7 @@ STN_STAGES = [(0, 4, 32, (2, 2)), (2, 32, 64, (2, 2)), (4, 64, 128, (2, 2)), (6,
 RPE_CHAIN = os.environ.get("TATT_RPE_CHAIN", "1") != "0"   # 0: one launch per step of the RPE recurrence (A/B runs)
 DEC_FUSED = os.environ.get("TATT_DEC_FUSED", "1") != "0"   # 0: the decoder as one launch per projection / attention / LayerNorm (A/B runs)
 WS_FLOATS = 48 * 1024 * 1024
+GRU_RES = os.environ.get("TATT_GRU_RES", "1") != "0"       # 0: "x + residual" of an SRB as an element-wise launch of its own (A/B runs)
 WGRAD192_WGS = int(os.environ.get("TATT_WGRAD192_WGS", "255"))
 WGRAD_WGS = int(os.environ.get("TATT_WGRAD_WGS", "480"))   # workgroups of a convolution weight-gradient launch (split-K factor = this / tiles)
 NODROP = (0, 0, 1.0, None)
@@ -477,8 +478,9 @@ class Engine:
             self.wpack["gru"] = pk
         return pk
 
-    def gru_block_fwd(self, pre, inputs, B, H, W, vertical, save, ctx, key):
-        """inputs: one or two [R,64] tensors whose channel concatenation is the block's input.  Returns out [R,64]."""
+    def gru_block_fwd(self, pre, inputs, B, H, W, vertical, save, ctx, key, res=None):
+        """inputs: one or two [R,64] tensors whose channel concatenation is the block's input.  Returns out [R,64]; with res
+        [R,64] returns (out, res + out), the sum written by the recurrence kernel itself."""
         P, R = self.P, B * H * W
         Wf, bf, _ = self._gru_fold()[pre]
         Cin = Wf.shape[1]
@@ -488,11 +490,15 @@ class Engine:
         gi = self.new(R, 192)
         self.L.gemm_cat(inputs[0], inputs[1] if len(inputs) > 1 else None, 64, Wf, gi, None, 0, bf, R, 192, Cin, 64, Cin, 1, 192, 0,
                         0, 0, self.pl)
-        self.L.gru32_fwd(gi, P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], P[pre + "gru.bias_hh_l0"],
-                         P[pre + "gru.bias_hh_l0_reverse"], out, sv, *self._seqmap(B, H, W, vertical))
+        whh = (P[pre + "gru.weight_hh_l0"], P[pre + "gru.weight_hh_l0_reverse"], P[pre + "gru.bias_hh_l0"], P[pre + "gru.bias_hh_l0_reverse"])
         if save:
             ctx[key] = (out, sv)
-        return out
+        if res is None:
+            self.L.gru32_fwd(gi, *whh, out, sv, *self._seqmap(B, H, W, vertical))
+            return out
+        out2 = self.new(R, 64)
+        self.L.gru32_fwd_res(gi, *whh, out, sv, res, out2, *self._seqmap(B, H, W, vertical))
+        return out, out2
 
     def gru_block_bwd(self, pre, dout, inputs, B, H, W, vertical, ctx, key, G, bn=None, ng=1):
         """inputs: list of (x [R,64], dx [R,64], acc) per concatenated input.  Writes parameter grads, input grads into dx.
@@ -981,9 +987,12 @@ class Engine:
         for i in range(m.srb_nums):
             pre = f"block{i + 2}."
             ca, ma, st1, cb, r2, st2 = first_convs if i == 0 else srb_convs(pre, blk)
-            r = self.gru_block_fwd(pre + "gru1.", [r2, tp_map], Bt, H, W, True, want_ctx, ctx, pre + "gru1")
-            s = self.new(Ra, 64)
-            L.axpby(blk, 1.0, r, 1.0, s, Ra * 64, 0)
+            if GRU_RES:
+                r, s = self.gru_block_fwd(pre + "gru1.", [r2, tp_map], Bt, H, W, True, want_ctx, ctx, pre + "gru1", res=blk)   # s = blk + r
+            else:
+                r = self.gru_block_fwd(pre + "gru1.", [r2, tp_map], Bt, H, W, True, want_ctx, ctx, pre + "gru1")
+                s = self.new(Ra, 64)
+                L.axpby(blk, 1.0, r, 1.0, s, Ra * 64, 0)
             out = self.gru_block_fwd(pre + "gru2.", [s], Bt, H, W, False, want_ctx, ctx, pre + "gru2")
             srbs.append((blk, ca, st1, ma, cb, st2, r2, s))
             blk = out

@@ -310,6 +310,11 @@ def test_gru32_fwd_bwd(vertical):
     out, sv = torch.empty(Rr, 64, device="cuda"), torch.empty(Rr, 2, 4, 32, device="cuda")
     L().gru32_fwd(gi, f32("weight_hh_l0"), f32("weight_hh_l0_reverse"), f32("bias_hh_l0"), f32("bias_hh_l0_reverse"), out, sv, *sm)
     close(out.view(B, H, W, 64), o, what="gru fwd")
+    # the variant that also writes res + out: same recurrence bit for bit, the sum exact
+    res = cu(rnd(Rr, 64, seed=11))
+    out_b, sv_b, out2 = torch.empty_like(out), torch.empty_like(sv), torch.empty_like(out)
+    L().gru32_fwd_res(gi, f32("weight_hh_l0"), f32("weight_hh_l0_reverse"), f32("bias_hh_l0"), f32("bias_hh_l0_reverse"), out_b, sv_b, res, out2, *sm)
+    assert torch.equal(out_b, out) and torch.equal(sv_b, sv) and torch.equal(out2, res + out)
     dgi, dghn, hp = torch.empty(Rr, 192, device="cuda"), torch.empty(Rr, 64, device="cuda"), torch.empty(Rr, 64, device="cuda")
     L().gru32_bwd(cu(dout.reshape(Rr, 64)), out, sv, f32("weight_hh_l0"), f32("weight_hh_l0_reverse"), dgi, dghn, hp, *sm)
     dgh = dgi.clone()                                                        # dgh = dgi with the n gate replaced by dghn (= dn * r)
