@@ -232,6 +232,14 @@ int tatt_pixshuf_mish_bwd(const float* x, const float* dy, float* dx, int B, int
 int tatt_sigmoid_to_nchw(const float* pre, float* sr, int B, int C, int HW, hipStream_t stream);
 int tatt_sigmoid_bwd_to_nhwc(const float* sr, const float* dsr, float* dpre, int B, int C, int HW, hipStream_t stream);
 int tatt_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int kh, int kw, hipStream_t stream);
+/* conv3x3_block's BatchNorm2d + ReLU and the MaxPool2d behind it (model/stn_head.py:19-20, :38-44), and stn_fc1's BatchNorm1d + ReLU
+ * (:51-52), on the small maps of the STN head as ONE launch per direction (training mode: batch statistics, running statistics
+ * updated): at most 1024 pooling windows (tatt_bn_pool_small_supported), window kh x kw in {1x1 (no pool), 2x2, 1x2}, C % 4 == 0.
+ * act_out = relu(bn(x)) is kept for the backward call, which routes dpooled to the first maximum of each window
+ * (tatt_maxpool_bwd's rule) and ACCUMULATES dgamma / dbeta. */
+size_t tatt_bn_pool_small_supported(int B, int H, int W, int C, int kh, int kw);   /* 1: the pair below takes this shape */
+int tatt_bn_pool_small_fwd(const float* x, float* stat, const float* gamma, const float* beta, float* run_mean, float* run_var, float* act_out, float* pooled, int B, int H, int W, int C, int kh, int kw, float eps, float momentum, hipStream_t stream);
+int tatt_bn_pool_small_bwd(const float* x, const float* act, const float* dpooled, const float* stat, const float* gamma, float* dx, float* dgamma, float* dbeta, int B, int H, int W, int C, int kh, int kw, hipStream_t stream);
 int tatt_maxpool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int kh, int kw, hipStream_t stream);
 int tatt_tp_rows(const float* tp, long sB, long sK, long sL, float* out, int B, int K, int L, hipStream_t stream);
 int tatt_pe_dropout(const float* pe, float* pos, int B, int L, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, hipStream_t stream);

@@ -520,6 +520,200 @@ inline void bn_blocking(int R, int* nblk, int* rpb) {
   *nblk = cdiv(R, rows_per_blk);
 }
 
+// ---- BatchNorm(training) + ReLU + MaxPool of the STN head's small maps as ONE launch per direction ------------------------------
+// The last four convolution stages of the STN head (model/stn_head.py:37-62: maps of 4x16 and smaller) and its fc1 BatchNorm work on
+// at most 4096 rows; as statistics-partial / statistics-final / apply / max-pool launches they are four dependent launches of a
+// few microseconds each on the critical path of the step, backward as many.  Channels are independent, so a workgroup that owns 4
+// channels needs no other workgroup: it sums its [R,4] strip (two passes over registers: mean, then M2), updates the running
+// statistics, applies gamma / beta / ReLU, writes the activation and the pooled map.  Thread = (float4 channel lane, window lane);
+// a thread keeps its pooling windows in registers (at most SM_NW windows of KH*KW rows).
+// Four-wave workgroups of four channels: big workgroups (1024 threads, 8-16 channels) were faster alone but waited for a CU with
+// sixteen free wave slots while the RPE chain and the weight-gradient strands hold theirs -- the step got slower, not faster.
+constexpr int SM_CL = 1, SM_CH = 4 * SM_CL, SM_NW = 4, SM_THR = 256, SM_WL = SM_THR / SM_CL;
+
+__device__ __forceinline__ float4 sm_bsum4(float4 v, float4* red, int tid) {  // sum over the window lanes of one channel lane
+#pragma unroll
+  for (int o = SM_CL; o < 64; o <<= 1) {
+    v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+  }
+  if ((tid & 63) < SM_CL) red[(tid >> 6) * SM_CL + (tid & (SM_CL - 1))] = v;
+  __syncthreads();
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int w = 0; w < SM_THR / 64; ++w) {
+    const float4 u = red[w * SM_CL + (tid & (SM_CL - 1))];
+    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+  }
+  __syncthreads();
+  return t;
+}
+
+template <int KH, int KW>
+__global__ __launch_bounds__(SM_THR) void bn_pool_small_fwd(const float* __restrict__ x, float* __restrict__ stat, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                            float* __restrict__ run_var, float* __restrict__ act_out,
+                                                            float* __restrict__ pooled, int B, int H, int W, int C, float eps, float momentum) {
+  __shared__ float4 red[SM_THR / 64 * SM_CL];
+  constexpr int NR = KH * KW;
+  const int tid = threadIdx.x, cl = tid & (SM_CL - 1), wl = tid / SM_CL;
+  const int c = blockIdx.x * SM_CH + cl * 4;
+  const int OH = H / KH, OW = W / KW, nwin = B * OH * OW;
+  float4 v[SM_NW][NR];
+  int row0[SM_NW];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < SM_NW; ++k) {
+    const int w = wl + k * SM_WL;
+    const bool on = w < nwin;
+    const int wc = on ? w : 0;
+    const int ox = wc % OW, q = wc / OW, oy = q % OH, b = q / OH;
+    row0[k] = (b * H + oy * KH) * W + ox * KW;
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+      for (int d = 0; d < KW; ++d) {
+        float4 t = *reinterpret_cast<const float4*>(x + (long)(row0[k] + a * W + d) * C + c);
+        if (!on) t = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[k][a * KW + d] = t;
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+  }
+  const float R = (float)(nwin * NR);
+  s = sm_bsum4(s, red, tid);
+  const float4 mean = make_float4(s.x / R, s.y / R, s.z / R, s.w / R);
+  float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < SM_NW; ++k) {
+    if (wl + k * SM_WL < nwin) {
+#pragma unroll
+      for (int e = 0; e < NR; ++e) {
+        const float dx = v[k][e].x - mean.x, dy = v[k][e].y - mean.y, dz = v[k][e].z - mean.z, dw = v[k][e].w - mean.w;
+        m2.x += dx * dx; m2.y += dy * dy; m2.z += dz * dz; m2.w += dw * dw;
+      }
+    }
+  }
+  m2 = sm_bsum4(m2, red, tid);
+  const float4 inv = make_float4(rsqrtf(m2.x / R + eps), rsqrtf(m2.y / R + eps), rsqrtf(m2.z / R + eps), rsqrtf(m2.w / R + eps));
+  if (wl == 0) {
+    *reinterpret_cast<float4*>(stat + c) = mean;
+    *reinterpret_cast<float4*>(stat + C + c) = inv;
+    if (run_mean) {
+      const float mu[4] = {mean.x, mean.y, mean.z, mean.w}, q2[4] = {m2.x, m2.y, m2.z, m2.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        run_mean[c + e] = (1.f - momentum) * run_mean[c + e] + momentum * mu[e];
+        const float unb = R > 1.f ? q2[e] / (R - 1.f) : q2[e] / R;
+        run_var[c + e] = (1.f - momentum) * run_var[c + e] + momentum * unb;
+      }
+    }
+  }
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+#pragma unroll
+  for (int k = 0; k < SM_NW; ++k) {
+    const int w = wl + k * SM_WL;
+    if (w >= nwin) continue;
+    float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+      for (int d = 0; d < KW; ++d) {
+        const float4 t = v[k][a * KW + d];
+        float4 o;
+        o.x = fmaxf((t.x - mean.x) * inv.x * ga.x + be.x, 0.f);
+        o.y = fmaxf((t.y - mean.y) * inv.y * ga.y + be.y, 0.f);
+        o.z = fmaxf((t.z - mean.z) * inv.z * ga.z + be.z, 0.f);
+        o.w = fmaxf((t.w - mean.w) * inv.w * ga.w + be.w, 0.f);
+        *reinterpret_cast<float4*>(act_out + (long)(row0[k] + a * W + d) * C + c) = o;
+        mx.x = fmaxf(mx.x, o.x); mx.y = fmaxf(mx.y, o.y); mx.z = fmaxf(mx.z, o.z); mx.w = fmaxf(mx.w, o.w);
+      }
+    if (NR > 1) *reinterpret_cast<float4*>(pooled + (long)w * C + c) = mx;
+  }
+}
+
+// backward of the same: dpooled [nwin,C] -> gradient of the max-pool (first maximum in scan order, as tatt_maxpool_bwd) -> ReLU
+// mask (act > 0) -> BatchNorm backward in training mode; dgamma / dbeta are ACCUMULATED.  Like the forward kernel the thread keeps its
+// windows in registers (g and xhat in place of the loaded activation and input): one round of loads, all of them in flight together.
+template <int KH, int KW>
+__global__ __launch_bounds__(SM_THR) void bn_pool_small_bwd(const float* __restrict__ x, const float* __restrict__ act, const float* __restrict__ dpooled,
+                                                            const float* __restrict__ stat, const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int H, int W, int C) {
+  __shared__ float4 red[SM_THR / 64 * SM_CL];
+  constexpr int NR = KH * KW;
+  const int tid = threadIdx.x, cl = tid & (SM_CL - 1), wl = tid / SM_CL;
+  const int c = blockIdx.x * SM_CH + cl * 4;
+  const int OH = H / KH, OW = W / KW, nwin = B * OH * OW;
+  float4 g[SM_NW][NR], xh[SM_NW][NR], dp[SM_NW];   // loaded as (act, x, dpooled); g / xhat after the first loop
+  int row0[SM_NW];
+#pragma unroll
+  for (int k = 0; k < SM_NW; ++k) {
+    const int w = wl + k * SM_WL;
+    const int wc = w < nwin ? w : 0;
+    const int ox = wc % OW, q = wc / OW, oy = q % OH, b = q / OH;
+    row0[k] = (b * H + oy * KH) * W + ox * KW;
+    dp[k] = *reinterpret_cast<const float4*>(dpooled + (long)wc * C + c);
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+      for (int d = 0; d < KW; ++d) {
+        g[k][a * KW + d] = *reinterpret_cast<const float4*>(act + (long)(row0[k] + a * W + d) * C + c);
+        xh[k][a * KW + d] = *reinterpret_cast<const float4*>(x + (long)(row0[k] + a * W + d) * C + c);
+      }
+  }
+  const float4 mean = *reinterpret_cast<const float4*>(stat + c), inv = *reinterpret_cast<const float4*>(stat + C + c);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  auto lane = [](float4& v, int e) -> float& { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
+#pragma unroll
+  for (int k = 0; k < SM_NW; ++k) {
+    const bool on = wl + k * SM_WL < nwin;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int am = 0;
+      float m = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const float av = lane(g[k][i], e);
+        if (av > m) { m = av; am = i; }
+      }
+      const float mu = lane(const_cast<float4&>(mean), e), iv = lane(const_cast<float4&>(inv), e), dpe = lane(dp[k], e);
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const float gv = (on && i == am && lane(g[k][i], e) > 0.f) ? dpe : 0.f;
+        const float xv = (lane(xh[k][i], e) - mu) * iv;
+        lane(g[k][i], e) = gv;
+        lane(xh[k][i], e) = xv;
+        lane(s1, e) += gv;
+        lane(s2, e) += gv * xv;
+      }
+    }
+  }
+  const float4 t1 = sm_bsum4(s1, red, tid);
+  const float4 t2 = sm_bsum4(s2, red, tid);
+  if (wl == 0) {
+    float4 dg = *reinterpret_cast<float4*>(dgamma + c), db = *reinterpret_cast<float4*>(dbeta + c);
+    dg.x += t2.x; dg.y += t2.y; dg.z += t2.z; dg.w += t2.w;
+    db.x += t1.x; db.y += t1.y; db.z += t1.z; db.w += t1.w;
+    *reinterpret_cast<float4*>(dgamma + c) = dg;
+    *reinterpret_cast<float4*>(dbeta + c) = db;
+  }
+  const float invR = 1.f / (float)(nwin * NR);
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+  const float4 k0 = make_float4(ga.x * inv.x, ga.y * inv.y, ga.z * inv.z, ga.w * inv.w);
+  const float4 m1 = make_float4(t1.x * invR, t1.y * invR, t1.z * invR, t1.w * invR), m2 = make_float4(t2.x * invR, t2.y * invR, t2.z * invR, t2.w * invR);
+#pragma unroll
+  for (int k = 0; k < SM_NW; ++k) {
+    if (wl + k * SM_WL >= nwin) continue;
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+      for (int d = 0; d < KW; ++d) {
+        const float4 gv = g[k][a * KW + d], xv = xh[k][a * KW + d];
+        *reinterpret_cast<float4*>(dx + (long)(row0[k] + a * W + d) * C + c) =
+            make_float4(k0.x * (gv.x - m1.x - xv.x * m2.x), k0.y * (gv.y - m1.y - xv.y * m2.y), k0.z * (gv.z - m1.z - xv.z * m2.z),
+                        k0.w * (gv.w - m1.w - xv.w * m2.w));
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -636,6 +830,44 @@ int tatt_ln_bwd(const float* v, const float* dy, float dyscale, const float* gam
   TATT_LAUNCH_CHECK("ln_bwd");
   hipLaunchKernelGGL(ln_bwd_final, dim3(4), dim3(256), 0, st, workspace, nblk, dgamma, dbeta, accumulate_params);
   TATT_LAUNCH_CHECK("ln_bwd_final");
+  return TATT_OK;
+}
+
+// One-launch BatchNorm (batch statistics, running-statistic update) + ReLU + max-pool (kh x kw, stride = window; 1 x 1 = none) of a
+// small NHWC map x [B,H,W,C]: stat [2][C] = (mean, invstd), act_out [B,H,W,C] = relu(bn(x)), pooled [B,H/kh,W/kw,C] (unused for 1 x 1).
+size_t tatt_bn_pool_small_supported(int B, int H, int W, int C, int kh, int kw) {
+  const bool pool_ok = (kh == 1 && kw == 1) || (kh == 2 && kw == 2) || (kh == 1 && kw == 2);
+  return pool_ok && B > 0 && H > 0 && W > 0 && C > 0 && C % SM_CH == 0 && H % kh == 0 && W % kw == 0 &&
+         (long)B * (H / kh) * (W / kw) <= (long)SM_NW * SM_WL;
+}
+
+int tatt_bn_pool_small_fwd(const float* x, float* stat, const float* gamma, const float* beta, float* run_mean, float* run_var, float* act_out,
+                           float* pooled, int B, int H, int W, int C, int kh, int kw, float eps, float momentum, hipStream_t st) {
+  TATT_CHECK_ARG(tatt_bn_pool_small_supported(B, H, W, C, kh, kw), "tatt_bn_pool_small_fwd: need C %% 4 == 0, a 1x1 / 2x2 / 1x2 window that divides "
+                 "the map and at most %d windows (got B=%d H=%d W=%d C=%d %dx%d)", SM_NW * SM_WL, B, H, W, C, kh, kw);
+  TATT_CHECK_ARG(x && stat && gamma && beta && act_out && (pooled || kh * kw == 1) && ((run_mean == nullptr) == (run_var == nullptr)),
+                 "tatt_bn_pool_small_fwd: null pointer");
+#define SM_FWD(a, b) hipLaunchKernelGGL((bn_pool_small_fwd<a, b>), dim3(C / SM_CH), dim3(SM_THR), 0, st, x, stat, gamma, beta, run_mean, run_var, act_out, pooled, B, H, W, C, eps, momentum)
+  if (kh == 2) SM_FWD(2, 2);
+  else if (kw == 2) SM_FWD(1, 2);
+  else SM_FWD(1, 1);
+#undef SM_FWD
+  TATT_LAUNCH_CHECK("bn_pool_small_fwd");
+  return TATT_OK;
+}
+
+// dpooled: gradient of the pooled map (of act_out itself for a 1 x 1 window); dx = gradient of x; dgamma / dbeta are accumulated.
+int tatt_bn_pool_small_bwd(const float* x, const float* act, const float* dpooled, const float* stat, const float* gamma, float* dx,
+                           float* dgamma, float* dbeta, int B, int H, int W, int C, int kh, int kw, hipStream_t st) {
+  TATT_CHECK_ARG(tatt_bn_pool_small_supported(B, H, W, C, kh, kw), "tatt_bn_pool_small_bwd: unsupported shape (B=%d H=%d W=%d C=%d %dx%d)", B, H, W, C,
+                 kh, kw);
+  TATT_CHECK_ARG(x && act && dpooled && stat && gamma && dx && dgamma && dbeta, "tatt_bn_pool_small_bwd: null pointer");
+#define SM_BWD(a, b) hipLaunchKernelGGL((bn_pool_small_bwd<a, b>), dim3(C / SM_CH), dim3(SM_THR), 0, st, x, act, dpooled, stat, gamma, dx, dgamma, dbeta, B, H, W, C)
+  if (kh == 2) SM_BWD(2, 2);
+  else if (kw == 2) SM_BWD(1, 2);
+  else SM_BWD(1, 1);
+#undef SM_BWD
+  TATT_LAUNCH_CHECK("bn_pool_small_bwd");
   return TATT_OK;
 }
 

@@ -25,6 +25,7 @@ STN_STAGES = [(0, 4, 32, (2, 2)), (2, 32, 64, (2, 2)), (4, 64, 128, (2, 2)), (6,
 RPE_CHAIN = os.environ.get("TATT_RPE_CHAIN", "1") != "0"   # 0: one launch per step of the RPE recurrence (A/B runs)
 DEC_FUSED = os.environ.get("TATT_DEC_FUSED", "1") != "0"   # 0: the decoder as one launch per projection / attention / LayerNorm (A/B runs)
 WS_FLOATS = 48 * 1024 * 1024
+STN_SMALL = os.environ.get("TATT_STN_SMALL", "1") != "0"   # 0: the STN head's small maps through the generic BatchNorm / pool launches (A/B runs)
 GRU_RES = os.environ.get("TATT_GRU_RES", "1") != "0"       # 0: "x + residual" of an SRB as an element-wise launch of its own (A/B runs)
 WGRAD192_WGS = int(os.environ.get("TATT_WGRAD192_WGS", "255"))
 WGRAD_WGS = int(os.environ.get("TATT_WGRAD_WGS", "480"))   # workgroups of a convolution weight-gradient launch (split-K factor = this / tiles)
@@ -906,6 +907,19 @@ class Engine:
                 Rr = B * hh * ww
                 c = self.new(Rr, cout)
                 self.conv(h, P[pre + "0.weight"], P[pre + "0.bias"], c, B, hh, ww, cin, cout, 3, fp32=True)
+                kh, kw = pool or (1, 1)
+                if STN_SMALL and L.bn_pool_small_supported(B, hh, ww, cout, kh, kw):
+                    # the small maps: batch statistics, apply + ReLU and the max-pool as one launch (tatt_bn_pool_small_fwd)
+                    stat, a = self.new(2, cout), self.new(Rr, cout)
+                    hp = self.new(B * (hh // kh) * (ww // kw), cout) if pool is not None else None
+                    L.bn_pool_small_fwd(c, stat, P[pre + "1.weight"], P[pre + "1.bias"], P[pre + "1.running_mean"], P[pre + "1.running_var"],
+                                        a, hp, B, hh, ww, cout, kh, kw, 1e-5, 0.1)
+                    self._nbt.append(P[pre + "1.num_batches_tracked"])
+                    rec = [h, c, stat, a, hh, ww]
+                    h = a if pool is None else hp
+                    hh, ww = hh // kh, ww // kw
+                    stn_saved.append(rec)
+                    continue
                 a, stat = self.bn(pre + "1.", c, Rr, cout, True, 1)
                 rec = [h, c, stat, a, hh, ww]
                 if pool is not None:
@@ -919,7 +933,13 @@ class Engine:
             L.nhwc_to_nchw(h, f, B, 256, 2)                                   # flatten order of x.view(B,-1) on NCHW
             l1 = self.new(B, 512)
             self.linear(f, P["stn_head.stn_fc1.0.weight"], P["stn_head.stn_fc1.0.bias"], l1, B, 512, 512, fp32=True)
-            feat, stat1 = self.bn("stn_head.stn_fc1.1.", l1, B, 512, True, 1)
+            if STN_SMALL and L.bn_pool_small_supported(B, 1, 1, 512, 1, 1):
+                stat1, feat = self.new(2, 512), self.new(B, 512)
+                L.bn_pool_small_fwd(l1, stat1, P["stn_head.stn_fc1.1.weight"], P["stn_head.stn_fc1.1.bias"], P["stn_head.stn_fc1.1.running_mean"],
+                                    P["stn_head.stn_fc1.1.running_var"], feat, None, B, 1, 1, 512, 1, 1, 1e-5, 0.1)
+                self._nbt.append(P["stn_head.stn_fc1.1.num_batches_tracked"])
+            else:
+                feat, stat1 = self.bn("stn_head.stn_fc1.1.", l1, B, 512, True, 1)
             feat01 = self.new(B, 512)
             L.axpby(feat, 0.1, None, 0.0, feat01, B * 512, 0)
             ctrl = self.new(B, 40)
@@ -1260,7 +1280,12 @@ class Engine:
             dfeat = self.new(B, 512)
             self.linear_dx(dctrl, P["stn_head.stn_fc2.weight"], dfeat, B, 40, 512, fp32=True)
             axpby(dfeat, 0.1, None, 0.0, dfeat, B * 512, 0)
-            dl1 = self.bn_bwd("stn_head.stn_fc1.1.", l1, dfeat, stat1, B, 512, 1, True, G)
+            if STN_SMALL and L.bn_pool_small_supported(B, 1, 1, 512, 1, 1):   # feat01 = 0.1 relu(bn(l1)): the same sign as the activation
+                dl1 = self.new(B, 512)
+                L.bn_pool_small_bwd(l1, feat01, dfeat, stat1, P["stn_head.stn_fc1.1.weight"], dl1, G["stn_head.stn_fc1.1.weight"],
+                                    G["stn_head.stn_fc1.1.bias"], B, 1, 1, 512, 1, 1)
+            else:
+                dl1 = self.bn_bwd("stn_head.stn_fc1.1.", l1, dfeat, stat1, B, 512, 1, True, G)
             self.linear_dw(dl1, f, G["stn_head.stn_fc1.0.weight"], B, 512, 512, fp32=True)
             self.colsum(dl1, B, 512, G["stn_head.stn_fc1.0.bias"])
             df = self.new(B, 512)
@@ -1271,12 +1296,17 @@ class Engine:
                 pre = f"stn_head.stn_convnet.{idx}."
                 hin, c, stat, a, hh, ww = rec
                 Rr = B * hh * ww
-                if pool is not None:
-                    da = self.new(Rr, cout)
-                    L.maxpool_bwd(a, dh, da, B, hh, ww, cout, pool[0], pool[1])
+                kh, kw = pool or (1, 1)
+                if STN_SMALL and L.bn_pool_small_supported(B, hh, ww, cout, kh, kw):   # max-pool, ReLU and BatchNorm backward: one launch
+                    da, dc = dh, self.new(Rr, cout)
+                    L.bn_pool_small_bwd(c, a, dh, stat, P[pre + "1.weight"], dc, G[pre + "1.weight"], G[pre + "1.bias"], B, hh, ww, cout, kh, kw)
                 else:
-                    da = dh
-                dc = self.bn_bwd(pre + "1.", c, da, stat, Rr, cout, 1, True, G)
+                    if pool is not None:
+                        da = self.new(Rr, cout)
+                        L.maxpool_bwd(a, dh, da, B, hh, ww, cout, pool[0], pool[1])
+                    else:
+                        da = dh
+                    dc = self.bn_bwd(pre + "1.", c, da, stat, Rr, cout, 1, True, G)
                 if self.debug is not None:
                     self.debug[f"stn{idx}"] = (dh.clone(), da.clone(), dc.clone())
                 self.conv_wgrad(hin, dc, G[pre + "0.weight"], G[pre + "0.bias"], B, hh, ww, cin, cout, 3, fp32=True, bias_grad=False)  # BN in training mode

@@ -335,6 +335,56 @@ def test_gru32_fwd_bwd(vertical):
     close(dx.view(B, H, W, 64), x.grad, 5e-5, "gru dx")
 
 
+@pytest.mark.parametrize("B,H,W,C,kh,kw", [(64, 4, 16, 128, 2, 2), (64, 2, 8, 256, 2, 2), (64, 1, 4, 256, 1, 2), (64, 1, 2, 256, 1, 1),
+                                          (64, 1, 1, 512, 1, 1), (3, 2, 6, 24, 2, 2), (5, 1, 1, 8, 1, 1), (7, 3, 4, 16, 1, 2)])
+def test_bn_pool_small_vs_torch_and_generic_launches(B, H, W, C, kh, kw):
+    """tatt_bn_pool_small_fwd / _bwd (BatchNorm batch statistics + ReLU + max-pool of the STN head's small maps, model/stn_head.py:19-20,
+    :38-44, :51-52, one launch per direction) against fp64 torch and against the generic launches they replace."""
+    x = rnd(B, C, H, W, seed=1).double().requires_grad_(True)
+    ga, be = (1 + 0.2 * rnd(C, seed=2)).double().requires_grad_(True), (0.1 * rnd(C, seed=3)).double().requires_grad_(True)
+    rm0, rv0 = 0.1 * rnd(C, seed=4), 1 + 0.1 * rnd(C, seed=5).abs()
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    a = torch.relu(F.batch_norm(x, rm, rv, ga, be, True, 0.1, 1e-5))
+    y = F.max_pool2d(a, (kh, kw), (kh, kw)) if kh * kw > 1 else a
+    dy = rnd(*y.shape, seed=6)
+    y.backward(dy.double())
+    ref = lambda t: t.detach().permute(0, 2, 3, 1).contiguous()             # CPU fp64, NHWC
+    nhwc = lambda t: ref(t).float().cuda()
+    R, Rp = B * H * W, B * (H // kh) * (W // kw)
+    xd, gad, bed, dyd = nhwc(x).view(R, C), cu(ga.detach().float()), cu(be.detach().float()), nhwc(dy).view(Rp, C)
+    assert L().bn_pool_small_supported(B, H, W, C, kh, kw)
+    stat, act, pooled = torch.empty(2, C, device="cuda"), torch.empty(R, C, device="cuda"), torch.empty(Rp, C, device="cuda")
+    rmd, rvd = cu(rm0), cu(rv0)
+    L().bn_pool_small_fwd(xd, stat, gad, bed, rmd, rvd, act, pooled if kh * kw > 1 else None, B, H, W, C, kh, kw, 1e-5, 0.1)
+    close(act, ref(a).view(R, C), what="relu(bn(x))")
+    if kh * kw > 1:
+        close(pooled, ref(y).view(Rp, C), what="pooled")
+    close(rmd, rm, what="running_mean")
+    close(rvd, rv, what="running_var")
+    dx, dg, db = torch.empty(R, C, device="cuda"), torch.ones(C, device="cuda"), torch.ones(C, device="cuda")
+    L().bn_pool_small_bwd(xd, act, dyd, stat, gad, dx, dg, db, B, H, W, C, kh, kw)
+    close(dx, ref(x.grad).view(R, C), 5e-5, "dx")
+    close(dg - 1, ga.grad, 5e-5, "dgamma (accumulated onto ones)")
+    close(db - 1, be.grad, 5e-5, "dbeta (accumulated onto ones)")
+    if C % 4 == 0 and (C <= 256 or C % 256 == 0):
+        # the launches it replaces: statistics, apply, pool / pool backward, BatchNorm backward
+        stat2, rm2, rv2 = torch.empty(2, C, device="cuda"), cu(rm0), cu(rv0)
+        L().bn_stats(xd, C, R, C, 1e-5, 0.1, stat2, rm2, rv2, ws())
+        close(stat, stat2.cpu(), 1e-6, "stat")
+        close(rvd, rv2.cpu(), 1e-6, "running_var vs bn_stats")
+        a2 = torch.empty(R, C, device="cuda")
+        L().bn_apply(xd, C, stat2, gad, bed, None, C, a2, C, R, C, 1)
+        close(act, a2.cpu(), 1e-6, "act vs bn_apply")
+        da = dyd
+        if kh * kw > 1:
+            da = torch.empty(R, C, device="cuda")
+            L().maxpool_bwd(act, dyd, da, B, H, W, C, kh, kw)
+        dx2, dg2, db2 = torch.empty(R, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        L().bn_bwd(xd, C, da, C, stat, gad, bed, dx2, C, dg2, db2, R, C, 1, 1, 1, 0, ws())
+        close(dx, dx2.cpu(), 2e-5, "dx vs bn_bwd")
+        close(dg - 1, dg2.cpu(), 2e-5, "dgamma vs bn_bwd")
+
+
 @pytest.mark.parametrize("B,chain", [(5, False), (5, True), (64, True), (3, True)])
 def test_rpe_fused_steps_vs_torch_gru(B, chain):
     """tatt_rpe_step_fwd / _bwd (one launch per step of the GRU(1024 -> 2x512) that runs over the batch axis with the

@@ -1,7 +1,8 @@
 """Standalone timings (B=64 SRB shapes) of the BatchNorm-epilogue launches and their second halves: python tools/micro_bn.py"""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tatt_amd.lib import lib
 L = lib()
 B, H, W, C = 64, 16, 64, 64
