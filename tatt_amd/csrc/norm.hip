@@ -103,13 +103,15 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
 
 // block = 16 channels x (blockDim.x / 16) row lanes (64 with 1024 threads: the conv epilogues leave one partial per 128 rows, 512 of
 // them at B = 64): each lane Chan-merges a strided subset of the row blocks, then 8 lanes merge 8 lanes each, then lane 0 those 8
-__global__ __launch_bounds__(1024) void bn_stats_final(const float* __restrict__ partial, int nblk, int R, int C, int rows_per_blk, float eps,
-                                                        float momentum, float* __restrict__ stat, float* __restrict__ run_mean,
-                                                        float* __restrict__ run_var) {
-  __shared__ float sn[1024], sm[1024], s2[1024];
-  const int RLN = blockDim.x >> 4;
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+// (cpb = channels per block: 16 with 16 row lanes for few row blocks, 4 with 64 row lanes for many -- always a four-wave workgroup: a
+// sixteen-wave one waits for a CU with sixteen free wave slots while the weight-gradient strands and the RPE chain hold theirs)
+__global__ __launch_bounds__(256) void bn_stats_final(const float* __restrict__ partial, int nblk, int R, int C, int rows_per_blk, float eps,
+                                                       float momentum, float* __restrict__ stat, float* __restrict__ run_mean,
+                                                       float* __restrict__ run_var, int cpb) {
+  __shared__ float sn[256], sm[256], s2[256];
+  const int RLN = blockDim.x / cpb;
+  const int cl = threadIdx.x % cpb, rl = threadIdx.x / cpb;
+  const int c = blockIdx.x * cpb + cl;
   float n = 0.f, mean = 0.f, m2 = 0.f;
   if (c < C)
     for (int b = rl; b < nblk; b += RLN) {
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(1024) void bn_stats_final(const float* __restrict__
   if (RLN > 8) {  // second level: lanes 0..7 merge every 8th lane's result
     if (rl < 8) {
       n = 0.f; mean = 0.f; m2 = 0.f;
-      for (int j = rl; j < RLN; j += 8) chan_merge(n, mean, m2, sn[j * 16 + cl], sm[j * 16 + cl], s2[j * 16 + cl]);
+      for (int j = rl; j < RLN; j += 8) chan_merge(n, mean, m2, sn[j * cpb + cl], sm[j * cpb + cl], s2[j * cpb + cl]);
     }
     __syncthreads();
     if (rl < 8) { sn[threadIdx.x] = n; sm[threadIdx.x] = mean; s2[threadIdx.x] = m2; }
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(1024) void bn_stats_final(const float* __restrict__
   if (rl != 0 || c >= C) return;
   n = 0.f; mean = 0.f; m2 = 0.f;
   const int last = RLN > 8 ? 8 : RLN;
-  for (int j = 0; j < last; ++j) chan_merge(n, mean, m2, sn[j * 16 + cl], sm[j * 16 + cl], s2[j * 16 + cl]);
+  for (int j = 0; j < last; ++j) chan_merge(n, mean, m2, sn[j * cpb + cl], sm[j * cpb + cl], s2[j * cpb + cl]);
   float var = m2 / n;
   stat[c] = mean;
   stat[C + c] = rsqrtf(var + eps);
@@ -295,12 +297,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ x
 }
 
 // sums[2][C]; dgamma/dbeta (+)=.  block = 16 channels x (blockDim.x / 16) row lanes, every lane's loads independent of one another
-__global__ __launch_bounds__(1024) void bn_bwd_final(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-  __shared__ float r1[1024], r2[1024];
-  const int RLN = blockDim.x >> 4;
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+__global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int cpb) {
+  __shared__ float r1[256], r2[256];
+  const int RLN = blockDim.x / cpb;
+  const int cl = threadIdx.x % cpb, rl = threadIdx.x / cpb;
+  const int c = blockIdx.x * cpb + cl;
   float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
   if (c < C) {
     int b = rl;
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_final(const float* __restrict__ p
   if (RLN > 8) {
     float t1 = 0.f, t2 = 0.f;
     if (rl < 8)
-      for (int j = rl; j < RLN; j += 8) { t1 += r1[j * 16 + cl]; t2 += r2[j * 16 + cl]; }
+      for (int j = rl; j < RLN; j += 8) { t1 += r1[j * cpb + cl]; t2 += r2[j * cpb + cl]; }
     __syncthreads();
     if (rl < 8) { r1[threadIdx.x] = t1; r2[threadIdx.x] = t2; }
     __syncthreads();
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_final(const float* __restrict__ p
   if (rl != 0 || c >= C) return;
   float s1 = 0.f, s2 = 0.f;
   const int last = RLN > 8 ? 8 : RLN;
-  for (int j = 0; j < last; ++j) { s1 += r1[j * 16 + cl]; s2 += r2[j * 16 + cl]; }
+  for (int j = 0; j < last; ++j) { s1 += r1[j * cpb + cl]; s2 += r2[j * cpb + cl]; }
   sums[c] = s1;
   sums[C + c] = s2;
   if (dgamma) {
@@ -728,8 +730,8 @@ int tatt_bn_stats(const float* x, long ldx, int R, int C, float eps, float momen
   bn_blocking(R, &nblk, &rpb);
   hipLaunchKernelGGL(bn_stats_partial, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, rpb, workspace);
   TATT_LAUNCH_CHECK("bn_stats_partial");
-  hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, 16)), dim3(nblk > 128 ? 1024 : 256), 0, st, workspace, nblk, R, C, rpb, eps, momentum, stat, run_mean,
-                     run_var);
+  hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, nblk > 128 ? 4 : 16)), dim3(256), 0, st, workspace, nblk, R, C, rpb, eps, momentum, stat, run_mean,
+                     run_var, nblk > 128 ? 4 : 16);
   TATT_LAUNCH_CHECK("bn_stats_final");
   return TATT_OK;
 }
@@ -763,7 +765,7 @@ int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const floa
   float* sums = workspace + (size_t)BN_MAXBLK * 2 * C;
   hipLaunchKernelGGL(bn_bwd_reduce, dim3(nblk), dim3(256), 0, st, x, ldx, dy, lddy, stat, gamma, beta, R, C, act, rpb, workspace);
   TATT_LAUNCH_CHECK("bn_bwd_reduce");
-  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 16)), dim3(nblk > 128 ? 1024 : 256), 0, st, workspace, nblk, C, sums, dgamma, dbeta, accumulate_params);
+  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, nblk > 128 ? 4 : 16)), dim3(256), 0, st, workspace, nblk, C, sums, dgamma, dbeta, accumulate_params, nblk > 128 ? 4 : 16);
   TATT_LAUNCH_CHECK("bn_bwd_final");
 #define BN_BWD_APPLY(A) hipLaunchKernelGGL(bn_bwd_apply<A>, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, dy, lddy, stat, gamma, beta, sums, dx, lddx, R, C, train, accumulate_dx)
   if (act == 1) BN_BWD_APPLY(1);
@@ -780,8 +782,8 @@ int tatt_bn_stats_from_partial(const float* partial, int nblk, int rows_per_blk,
                                float* run_mean, float* run_var, hipStream_t st) {
   TATT_CHECK_ARG(partial && stat && nblk > 0 && rows_per_blk > 0 && (long)nblk * rows_per_blk >= R && (long)(nblk - 1) * rows_per_blk < R && C > 0,
                  "tatt_bn_stats_from_partial: bad arguments");
-  hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, 16)), dim3(nblk > 128 ? 1024 : 256), 0, st, partial, nblk, R, C, rows_per_blk, eps, momentum, stat, run_mean,
-                     run_var);
+  hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, nblk > 128 ? 4 : 16)), dim3(256), 0, st, partial, nblk, R, C, rows_per_blk, eps, momentum, stat, run_mean,
+                     run_var, nblk > 128 ? 4 : 16);
   TATT_LAUNCH_CHECK("bn_stats_final");
   return TATT_OK;
 }
@@ -793,7 +795,7 @@ int tatt_bn_bwd_from_partial(const float* x, long ldx, const float* g, long ldg,
                              int accumulate_params, int accumulate_dx, float* sums, hipStream_t st) {
   TATT_CHECK_ARG(x && g && stat && gamma && beta && partial && dx && sums && nblk > 0 && C % 4 == 0 && (C <= 256 || C % 256 == 0),
                  "tatt_bn_bwd_from_partial: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, 16)), dim3(nblk > 128 ? 1024 : 256), 0, st, partial, nblk, C, sums, dgamma, dbeta, accumulate_params);
+  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, nblk > 128 ? 4 : 16)), dim3(256), 0, st, partial, nblk, C, sums, dgamma, dbeta, accumulate_params, nblk > 128 ? 4 : 16);
   TATT_LAUNCH_CHECK("bn_bwd_final");
   hipLaunchKernelGGL(bn_bwd_apply<0>, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, g, ldg, stat, gamma, beta, sums, dx, lddx, R, C,
                      train, accumulate_dx);

@@ -25,6 +25,7 @@ STN_STAGES = [(0, 4, 32, (2, 2)), (2, 32, 64, (2, 2)), (4, 64, 128, (2, 2)), (6,
 RPE_CHAIN = os.environ.get("TATT_RPE_CHAIN", "1") != "0"   # 0: one launch per step of the RPE recurrence (A/B runs)
 DEC_FUSED = os.environ.get("TATT_DEC_FUSED", "1") != "0"   # 0: the decoder as one launch per projection / attention / LayerNorm (A/B runs)
 WS_FLOATS = 48 * 1024 * 1024
+STN_FC_SPLITK = int(os.environ.get("TATT_STN_FC_SPLITK", "8"))   # split-K factor of the STN head's fc products (1: none; A/B runs)
 STN_SMALL = os.environ.get("TATT_STN_SMALL", "1") != "0"   # 0: the STN head's small maps through the generic BatchNorm / pool launches (A/B runs)
 GRU_RES = os.environ.get("TATT_GRU_RES", "1") != "0"       # 0: "x + residual" of an SRB as an element-wise launch of its own (A/B runs)
 WGRAD192_WGS = int(os.environ.get("TATT_WGRAD192_WGS", "255"))
@@ -233,6 +234,20 @@ class Engine:
         self._guard(dx)
         self.L.gemm(dy, W, dx, None, R, K, N, lddy or N, 1, 1, ldw or K, lddx or K, 1, 0, 0, 0, acc, self.px if fp32 else self.pl, splitk,
                     self.ws if splitk > 1 else None)
+
+    def _tps_matrix(self, H, W):
+        """target_coordinate_repr @ inverse_kernel[:, :20] [H*W, 20] of the TPS grid (model/tps_spatial_transformer.py:99-102): a
+        product of two registered buffers, so it is formed once per engine and buffer storage, not once per forward pass."""
+        P = self.P
+        a, b = P["tps.target_coordinate_repr"], P["tps.inverse_kernel"]
+        key = (a.data_ptr(), a._version, b.data_ptr(), b._version, H, W)
+        if getattr(self, "_tps_key", None) != key:
+            Tm = self.new(H * W, 20)
+            self.L.gemm(a, b, Tm, None, H * W, 20, 23, 23, 1, 1, 23, 20, 1, 0, 0, 0, 0, 0, 1, None)
+            if torch.cuda.is_current_stream_capturing():        # a captured launch has not run yet: nothing to remember
+                return Tm
+            self._tps_key, self._tps_Tm = key, Tm
+        return self._tps_Tm
 
     def linear_dw(self, dy, x, dW, R, N, K, lddy=None, ldx=None, lddw=None, fp32=False):
         """dW[N,K] += dy[R,N]^T @ x[R,K]  (always accumulates into the gradient buffer)"""
@@ -932,7 +947,8 @@ class Engine:
             f = self.new(B, 512)
             L.nhwc_to_nchw(h, f, B, 256, 2)                                   # flatten order of x.view(B,-1) on NCHW
             l1 = self.new(B, 512)
-            self.linear(f, P["stn_head.stn_fc1.0.weight"], P["stn_head.stn_fc1.0.bias"], l1, B, 512, 512, fp32=True)
+            # few rows, K = 512: split-K (one workgroup per column tile walked sixteen k tiles on its own, 20 us)
+            self.linear(f, P["stn_head.stn_fc1.0.weight"], P["stn_head.stn_fc1.0.bias"], l1, B, 512, 512, fp32=True, splitk=STN_FC_SPLITK)
             if STN_SMALL and L.bn_pool_small_supported(B, 1, 1, 512, 1, 1):
                 stat1, feat = self.new(2, 512), self.new(B, 512)
                 L.bn_pool_small_fwd(l1, stat1, P["stn_head.stn_fc1.1.weight"], P["stn_head.stn_fc1.1.bias"], P["stn_head.stn_fc1.1.running_mean"],
@@ -943,10 +959,8 @@ class Engine:
             feat01 = self.new(B, 512)
             L.axpby(feat, 0.1, None, 0.0, feat01, B * 512, 0)
             ctrl = self.new(B, 40)
-            self.linear(feat01, P["stn_head.stn_fc2.weight"], P["stn_head.stn_fc2.bias"], ctrl, B, 40, 512, fp32=True)
-            Tm = self.new(H * W, 20)                                          # target_coordinate_repr @ inverse_kernel[:, :20]
-            L.gemm(P["tps.target_coordinate_repr"], P["tps.inverse_kernel"], Tm, None, H * W, 20, 23, 23, 1, 1, 23, 20,
-                   1, 0, 0, 0, 0, 0, 1, None)
+            self.linear(feat01, P["stn_head.stn_fc2.weight"], P["stn_head.stn_fc2.bias"], ctrl, B, 40, 512, fp32=True, splitk=2 * STN_FC_SPLITK)
+            Tm = self._tps_matrix(H, W)
             L.tps_sample_fwd(xq, ctrl, Tm, xs_q, None, B, 4, H, W)
             stn_ctx.append((stn_saved, f, l1, stat1, feat01, ctrl, Tm))
         if use_stn:
@@ -1289,7 +1303,7 @@ class Engine:
             self.linear_dw(dl1, f, G["stn_head.stn_fc1.0.weight"], B, 512, 512, fp32=True)
             self.colsum(dl1, B, 512, G["stn_head.stn_fc1.0.bias"])
             df = self.new(B, 512)
-            self.linear_dx(dl1, P["stn_head.stn_fc1.0.weight"], df, B, 512, 512, fp32=True)
+            self.linear_dx(dl1, P["stn_head.stn_fc1.0.weight"], df, B, 512, 512, fp32=True, splitk=STN_FC_SPLITK)
             dh = self.new(B * 2, 256)
             L.nchw_to_nhwc(df, dh, B, 256, 2)
             for (idx, cin, cout, pool), rec in zip(reversed(STN_STAGES), reversed(stn_saved)):
