@@ -1170,27 +1170,49 @@ __global__ __launch_bounds__(256, 2) void conv_c4_direct(const float* __restrict
   const int y0 = ty * C4_TH, x0 = tx * C4_TW;
   const int gy = hh * 4 + (lane >> 4), gx = (lane & 15) * C4_PX;  // this thread's pixels: row y0 + gy, columns x0 + gx .. + 3
   const float* Xb = X + (long)b * H * W * ldx;
-  float acc[C4_PX][4];
+  // output channels in pairs: v_pk_fma_f32 (two FMAs per lane and issue; the input value is the same for both halves -- op_sel
+  // picks it from its register, no splat copy).  Plain v_fma_f32 tops out at half the fp32 vector peak.
+  f32x2 acc[C4_PX][2];
 #pragma unroll
-  for (int p = 0; p < C4_PX; ++p)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
+  for (int p = 0; p < C4_PX; ++p) acc[p][0] = acc[p][1] = f32x2{0.f, 0.f};
   const int nchunk = Cin / (4 * C4_Q);
+  // Staging: every thread's share of the chunk (nine tile float4 + three weight float4) is fetched into registers with branch-free
+  // buffer loads (out-of-image halo and the tail of the index range: an out-of-range offset, which reads as 0) one chunk AHEAD, while
+  // the current chunk is multiplied, and parked in LDS between two barriers.  (With `if (in bounds) load; store` in a loop the loads
+  // went out one at a time and the staging, not the FMAs, was the kernel: 175 us for 70 us of arithmetic.)
+  constexpr int C4_NT = (C4_RH * C4_RW * C4_Q + 255) / 256, C4_NW = (C4_W4 + 255) / 256;
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(Xb), rsW = make_rsrc(Wp);
+  int voff[C4_NT], lidx[C4_NT];
+#pragma unroll
+  for (int k = 0; k < C4_NT; ++k) {
+    const int i = tid + 256 * k;
+    const bool valid = i < C4_RH * C4_RW * C4_Q;
+    const int qq = i % C4_Q, pos = i / C4_Q, r = pos / C4_RW, c = pos - r * C4_RW;
+    const int yy = y0 + r - C4_HALO, xx = x0 + c - C4_HALO;
+    const bool inb = valid && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    voff[k] = inb ? (int)((((long)yy * W + xx) * ldx + qq * 4) * 4) : BUF_OOB;
+    lidx[k] = valid ? (qq * C4_RH + r) * C4_RWP + c + (c >> 2) : -1;
+  }
+  float4 tv[C4_NT], wv[C4_NW];
+  auto fetch = [&](int ch) {
+#pragma unroll
+    for (int k = 0; k < C4_NT; ++k) tv[k] = bload4s(rsX, voff[k], ch * (C4_Q * 16));
+#pragma unroll
+    for (int k = 0; k < C4_NW; ++k) wv[k] = bload4s(rsW, tid + 256 * k < C4_W4 ? (tid + 256 * k) * 16 : BUF_OOB, ch * (C4_W4 * 16));
+  };
+  fetch(0);
   for (int ch = 0; ch < nchunk; ++ch) {
     __syncthreads();  // the previous chunk's window / weight reads are done
-    for (int i = tid; i < C4_RH * C4_RW * C4_Q; i += 256) {
-      const int qq = i % C4_Q, pos = i / C4_Q, r = pos / C4_RW, c = pos - r * C4_RW;
-      const int yy = y0 + r - C4_HALO, xx = x0 + c - C4_HALO;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-        v = *reinterpret_cast<const float4*>(Xb + ((long)yy * W + xx) * ldx + (ch * C4_Q + qq) * 4);
-      tile[(qq * C4_RH + r) * C4_RWP + c + (c >> 2)] = v;
-    }
+#pragma unroll
+    for (int k = 0; k < C4_NT; ++k)
+      if (lidx[k] >= 0) tile[lidx[k]] = tv[k];
     // the chunk's weights [quad][tap][ci][co]: read below with wave-uniform addresses (LDS broadcast).  Scalar loads would be the
     // natural fit, but the 83 KB of weights overflow the scalar cache and every s_load then waits on L2 with lgkmcnt(0)
-    const float4* wg = reinterpret_cast<const float4*>(Wp) + (long)ch * C4_W4;
-    for (int i = tid; i < C4_W4; i += 256) wl[i] = wg[i];
+#pragma unroll
+    for (int k = 0; k < C4_NW; ++k)
+      if (tid + 256 * k < C4_W4) wl[tid + 256 * k] = wv[k];
     __syncthreads();
+    fetch(min(ch + 1, nchunk - 1));  // in flight under the FMAs below (the last trip re-reads its own chunk: no branch)
     const float4* wq = wl + q * C4_KS * C4_KS * 4;
     const float4* trow = tile + (q * C4_RH + gy) * C4_RWP;
 #pragma unroll 1
@@ -1202,13 +1224,14 @@ __global__ __launch_bounds__(256, 2) void conv_c4_direct(const float* __restrict
 #pragma unroll
       for (int dx = 0; dx < C4_KS; ++dx) {
         const float4 w0 = wr[dx * 4], w1 = wr[dx * 4 + 1], w2 = wr[dx * 4 + 2], w3 = wr[dx * 4 + 3];  // rows ci = 0..3 of [ci][co]
+        const f32x2 w0a = {w0.x, w0.y}, w0b = {w0.z, w0.w}, w1a = {w1.x, w1.y}, w1b = {w1.z, w1.w};
+        const f32x2 w2a = {w2.x, w2.y}, w2b = {w2.z, w2.w}, w3a = {w3.x, w3.y}, w3b = {w3.z, w3.w};
 #pragma unroll
         for (int p = 0; p < C4_PX; ++p) {
           const float4 xv = win[p + dx];
-          acc[p][0] = fmaf(xv.w, w3.x, fmaf(xv.z, w2.x, fmaf(xv.y, w1.x, fmaf(xv.x, w0.x, acc[p][0]))));
-          acc[p][1] = fmaf(xv.w, w3.y, fmaf(xv.z, w2.y, fmaf(xv.y, w1.y, fmaf(xv.x, w0.y, acc[p][1]))));
-          acc[p][2] = fmaf(xv.w, w3.z, fmaf(xv.z, w2.z, fmaf(xv.y, w1.z, fmaf(xv.x, w0.z, acc[p][2]))));
-          acc[p][3] = fmaf(xv.w, w3.w, fmaf(xv.z, w2.w, fmaf(xv.y, w1.w, fmaf(xv.x, w0.w, acc[p][3]))));
+          const f32x2 sx = {xv.x, xv.x}, sy = {xv.y, xv.y}, sz = {xv.z, xv.z}, sw = {xv.w, xv.w};
+          acc[p][0] = __builtin_elementwise_fma(sw, w3a, __builtin_elementwise_fma(sz, w2a, __builtin_elementwise_fma(sy, w1a, __builtin_elementwise_fma(sx, w0a, acc[p][0]))));
+          acc[p][1] = __builtin_elementwise_fma(sw, w3b, __builtin_elementwise_fma(sz, w2b, __builtin_elementwise_fma(sy, w1b, __builtin_elementwise_fma(sx, w0b, acc[p][1]))));
         }
       }
     }
@@ -1218,7 +1241,7 @@ __global__ __launch_bounds__(256, 2) void conv_c4_direct(const float* __restrict
   float4* red = smem;
   const int pix0 = gy * C4_TW + gx;
 #pragma unroll
-  for (int p = 0; p < C4_PX; ++p) red[q * (C4_TH * C4_TW) + pix0 + p] = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+  for (int p = 0; p < C4_PX; ++p) red[q * (C4_TH * C4_TW) + pix0 + p] = make_float4(acc[p][0].x, acc[p][0].y, acc[p][1].x, acc[p][1].y);
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < C4_TH * C4_TW / 256; ++k) {
@@ -1677,6 +1700,7 @@ int tatt_conv_skinny_fwd(const float* X, const float* Wt, const float* bias, flo
                  "tatt_conv_skinny_fwd: a %dx%d convolution with %d output channels needs ldx %% 4 == 0 and a 16-byte aligned X (ldx %ld)",
                  KH, KW, Cout, ldx);
   if (c4_direct_ok(Cin, Cout, KH, KW, ldx, X)) {  // 9x9, four output channels: direct convolution, no planar intermediate
+    TATT_CHECK_ARG((long)H * W * ldx * 4 < GIB2, "tatt_conv_skinny_fwd: one image must span less than 2 GiB (32-bit buffer offsets)");
     hipLaunchKernelGGL(conv_c4_pack_w, dim3(cdiv((long)T * Cin * 4, 256)), dim3(256), 0, st, Wt, workspace, Cin, T, w_sn, w_sci, w_base, w_stap);
     TATT_LAUNCH_CHECK("conv_c4_pack_w");
     const int tiles_x = cdiv(W, C4_TW), tiles_y = cdiv(H, C4_TH);
