@@ -25,6 +25,9 @@ STN_STAGES = [(0, 4, 32, (2, 2)), (2, 32, 64, (2, 2)), (4, 64, 128, (2, 2)), (6,
 RPE_CHAIN = os.environ.get("TATT_RPE_CHAIN", "1") != "0"   # 0: one launch per step of the RPE recurrence (A/B runs)
 DEC_FUSED = os.environ.get("TATT_DEC_FUSED", "1") != "0"   # 0: the decoder as one launch per projection / attention / LayerNorm (A/B runs)
 WS_FLOATS = 48 * 1024 * 1024
+RPE_TAIL_ON_SIDE = os.environ.get("TATT_RPE_TAIL_ON_SIDE", "1") != "0"   # 0: the main stream joins the RPE chain before the STN head's backward pass (A/B runs)
+ENC_BWD_FORK = os.environ.get("TATT_ENC_BWD_FORK", "1") != "0"   # 0: the text branch's backward pass on the main stream (A/B runs)
+RPE_FINISH_EARLY = os.environ.get("TATT_RPE_FINISH_EARLY", "1") != "0"   # 0: join the RPE chain after the STN head's backward pass (A/B runs)
 STN_FC_SPLITK = int(os.environ.get("TATT_STN_FC_SPLITK", "8"))   # split-K factor of the STN head's fc products (1: none; A/B runs)
 STN_SMALL = os.environ.get("TATT_STN_SMALL", "1") != "0"   # 0: the STN head's small maps through the generic BatchNorm / pool launches (A/B runs)
 GRU_RES = os.environ.get("TATT_GRU_RES", "1") != "0"       # 0: "x + residual" of an SRB as an element-wise launch of its own (A/B runs)
@@ -85,7 +88,8 @@ class Engine:
         self._rpe_chain_ok = None
         self.dec_fused = DEC_FUSED   # the TP interpreter's decoder as tatt_dec_fwd / tatt_dec_bwd (False: one launch per op; tests compare the two)
         self._rpe_sync = self._rpe_sync_b = None
-        self.ws_side = None
+        self.ws_side = self.ws_enc = self.ws_side_b = None
+        self._strand, self._wgrad_ws = False, None
         self.wgrad_mode = os.environ.get("TATT_WGRAD_STREAM", "batch")
         if self.wgrad_mode not in ("batch", "off"):
             raise RuntimeError("TATT_WGRAD_STREAM must be 'batch' or 'off'")
@@ -132,6 +136,8 @@ class Engine:
         issued by then.  The operands are kept alive until the next join (the caching allocator must not hand their memory
         to a later main-stream tensor), and the gradients are remembered by storage so that _guard() can order a later
         in-place update of one of them after the queued reads."""
+        if self._wgrad_ws is not None:                        # a side strand launching its own weight gradients in place (RPE tail)
+            return fn(self._wgrad_ws)
         if self.wgrad_mode != "batch":
             return fn(self.ws)
         self._w_defer.append(fn)                              # launched on the weight-gradient stream at the next _w_flush()
@@ -176,6 +182,8 @@ class Engine:
     def _guard(self, t):
         """Call before the main stream writes `t` in place: if a pending weight-gradient kernel still reads it, join first."""
         if self._w_pending and t is not None and t.untyped_storage().data_ptr() in self._w_pending:
+            if self._strand:
+                raise RuntimeError("a side strand of the backward pass would have to join the weight-gradient streams (guarded in-place write)")
             self._w_join()
 
     def rpe_chain(self):
@@ -1233,10 +1241,8 @@ class Engine:
                         L.rpe_step_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
                                        dgh_all[0, s + 1] if s + 1 < B else None, dgh_all[0, s], dgi_sum, whhT, s, B, dsg, dsh)
 
-        def rpe_finish():
-            if owner is not None:
-                return
-            main.wait_stream(side)
+        def rpe_tail():
+            """What follows the chain: its weight gradients, the gradient of the (time-invariant) input and of init_factor."""
             dxg = self.new(64, 1024)
             for dd, sfx in enumerate(["", "_reverse"]):
                 self.linear_dw(dgh_all[dd], hstep[dd], G[g + "weight_hh_l0" + sfx], 64 * B, 1536, 512, fp32=True)
@@ -1245,28 +1251,74 @@ class Engine:
                 self.colsum(dgi_sum[dd], 64, 1536, G[g + "bias_ih_l0" + sfx])
                 self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd, splitk=8, fp32=True)
             L.rpe_scatter_dx(dxg, G[ig + "init_factor.weight"], 1)
+
+        rpe_on_side = RPE_TAIL_ON_SIDE and owner is None and side != main and self.wgrad_mode == "batch"
+        if rpe_on_side:
+            # The chain's tail stays on the chain's own stream, with a workspace of its own and its weight-gradient kernels launched
+            # in place (not through the queue of the weight-gradient streams): it starts the moment the chain ends, and the main
+            # stream -- which used to wait for the chain here before the STN head's backward pass -- joins at the end of the pass.
+            need = max(1536 * 512 * self._splitk(1536, 512, 64 * B), 8 * 64 * 1024, 1 << 20)   # split-K slabs of the W_hh gradient / of dxg
+            if self.ws_side_b is None or self.ws_side_b.device != self.dev or self.ws_side_b.numel() < need:
+                self.ws_side_b = torch.empty(need, device=self.dev)
+            ws_keep, self.ws, self._wgrad_ws = self.ws, self.ws_side_b, self.ws_side_b
+            with torch.cuda.stream(side):
+                rpe_tail()
+            self.ws, self._wgrad_ws = ws_keep, None
+
+        def rpe_finish():
+            if owner is not None or rpe_on_side:
+                return
+            main.wait_stream(side)
+            rpe_tail()
+
+        def rpe_join():
+            if rpe_on_side:
+                main.wait_stream(side)
         # encoder, per pass (the text branch runs once per pass: its dropout masks differ); the passes' gradients wrt the doubled
-        # encoder input (shared) are summed
-        e = tr + "encoder.layers.0."
-        dsrc2 = self.new(Rt, 64)
-        for q_, (pos, qk, att_e, v1e, s1, ffn_e, v2e, mem, kin) in enumerate(text):
-            cf = cfgs[q_]
-            ds1 = self.new(Rt, 64)
-            dfe = self.ln_bwd(e + "norm2.", v2e, dmems[q_], 1.0, ds1, 0, cf("enc_drop2"), Rt, G, True)
-            self.ffn_bwd(e, dfe if dfe is not None else ds1, ffn_e, s1, Rt, cf("enc_ffn"), G, ds1)
-            dsq = dsrc2 if q_ == 0 else self.new(Rt, 64)
-            dae = self.ln_bwd(e + "norm1.", v1e, ds1, 1.0, dsq, 0, cf("enc_drop1"), Rt, G, True)
-            dqk = self.new(Rt, 64)
-            self.mha_bwd(e + "self_attn.", dae if dae is not None else dsq, att_e, qk, qk, src2, B, 26, cf("enc_attn"), G,
-                         dqk, dqk, dsq, 0, 1, 1)
-            axpby(dqk, 1.0, None, 0.0, dsq, Rt * 64, 1)
-            if q_ > 0:
-                axpby(dsq, 1.0, None, 0.0, dsrc2, Rt * 64, 1)
-        dt = self.new(Rt, 64)
-        axpby(dsrc2, 2.0, None, 0.0, dt, Rt * 64, 0)
-        dt0 = self.new(Rt, 64)
-        L.prelu_bwd(t0, P[ig + "activation.weight"], dt, dt0, G[ig + "activation.weight"], 1, Rt * 64, self.ws)
-        self.linear_dwb(dt0, tpr, G[ig + "fc_in.weight"], G[ig + "fc_in.bias"], Rt, 64, K)
+        # encoder input (shared) are summed.  Nothing downstream on the image chain reads what this produces (parameter gradients
+        # only), so the two dozen small launches run on the text branch's stream beside block1's and the STN head's backward pass,
+        # with a workspace of their own; the main stream joins before the weight-gradient queue they fed is flushed.
+        enc = self.enc_stream() if ENC_BWD_FORK else main
+        enc.wait_stream(main)
+        if self.ws_enc is None or self.ws_enc.device != self.dev:
+            self.ws_enc = torch.empty(1 << 20, device=self.dev)
+        forked = enc != main
+        ws_main, self.ws = self.ws, (self.ws_enc if forked else self.ws)
+        self._strand = forked                                 # a guarded write must not join the weight-gradient streams from here
+        with torch.cuda.stream(enc):
+            e = tr + "encoder.layers.0."
+            dsrc2 = self.new(Rt, 64)
+            for q_, (pos, qk, att_e, v1e, s1, ffn_e, v2e, mem, kin) in enumerate(text):
+                cf = cfgs[q_]
+                ds1 = self.new(Rt, 64)
+                dfe = self.ln_bwd(e + "norm2.", v2e, dmems[q_], 1.0, ds1, 0, cf("enc_drop2"), Rt, G, True)
+                if dfe is None:
+                    # p = 0: the residual branch's gradient IS ds1, which the queued weight-gradient kernels of the FFN read while its
+                    # input gradient is added onto ds1 -- a guarded write, i.e. a join of the weight-gradient streams in mid-chain.
+                    # The branch gets a copy instead (one 6.6 k-element launch).
+                    dfe = self.new(Rt, 64)
+                    L.axpby(ds1, 1.0, None, 0.0, dfe, Rt * 64, 0)
+                self.ffn_bwd(e, dfe, ffn_e, s1, Rt, cf("enc_ffn"), G, ds1)
+                dsq = dsrc2 if q_ == 0 else self.new(Rt, 64)
+                dae = self.ln_bwd(e + "norm1.", v1e, ds1, 1.0, dsq, 0, cf("enc_drop1"), Rt, G, True)
+                if dae is None:                                 # likewise for the attention branch
+                    dae = self.new(Rt, 64)
+                    L.axpby(dsq, 1.0, None, 0.0, dae, Rt * 64, 0)
+                dqk = self.new(Rt, 64)
+                self.mha_bwd(e + "self_attn.", dae, att_e, qk, qk, src2, B, 26, cf("enc_attn"), G, dqk, dqk, dsq, 0, 1, 1)
+                axpby(dqk, 1.0, None, 0.0, dsq, Rt * 64, 1)
+                if q_ > 0:
+                    axpby(dsq, 1.0, None, 0.0, dsrc2, Rt * 64, 1)
+            dt = self.new(Rt, 64)
+            axpby(dsrc2, 2.0, None, 0.0, dt, Rt * 64, 0)
+            dt0 = self.new(Rt, 64)
+            L.prelu_bwd(t0, P[ig + "activation.weight"], dt, dt0, G[ig + "activation.weight"], 1, Rt * 64, self.ws)
+            self.linear_dwb(dt0, tpr, G[ig + "fc_in.weight"], G[ig + "fc_in.bias"], Rt, 64, K)
+        self.ws, self._strand = ws_main, False
+
+        def enc_join():
+            if forked:
+                main.wait_stream(enc)
 
         # ---- block1 ------------------------------------------------------------------------------------------------
         dc1 = self.new(Ra, 64)
@@ -1274,7 +1326,9 @@ class Engine:
         xs = ctx["xs"]
         self.conv_wgrad(xs, dc1, G["block1.0.weight"], G["block1.0.bias"], Bt, H, W, 4, 64, 9)
         if not ctx["use_stn"]:
+            enc_join()
             rpe_finish()
+            rpe_join()
             on_stage("head")
             on_stage("infogen")
             return
@@ -1285,9 +1339,13 @@ class Engine:
             dctrl = self.new(B, 40)
             L.tps_sample_bwd(ctx["x"][q_], ctrl, Tm, dxs[q_ * R0:], dctrl, B, 4, H, W, 0)
             if q_ == 0:
+                enc_join()                                      # the flushes below launch weight gradients queued by the text branch
+            if q_ == 0 and RPE_FINISH_EARLY:
                 # The RPE chain (forked after the decoder) has ended by now at the benchmark shapes: its input-gradient GEMMs go here and
                 # its weight gradients join the queue, so that they overlap with the STN head's backward pass instead of trailing it.
                 rpe_finish()
+                self._w_flush()
+            elif q_ == 0:
                 self._w_flush()
             self.linear_dw(dctrl, feat01, G["stn_head.stn_fc2.weight"], B, 40, 512, fp32=True)
             self.colsum(dctrl, B, 40, G["stn_head.stn_fc2.bias"])
@@ -1329,6 +1387,9 @@ class Engine:
                     self.conv_dgrad(dc, P[pre + "0.weight"], dh, B, hh, ww, cin, cout, 3, fp32=True)
                 if idx in (8, 4):
                     self._w_flush()
+        if not RPE_FINISH_EARLY:
+            rpe_finish()
+        rpe_join()
         on_stage("head")
         on_stage("infogen")
 
