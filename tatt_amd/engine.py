@@ -25,6 +25,7 @@ STN_STAGES = [(0, 4, 32, (2, 2)), (2, 32, 64, (2, 2)), (4, 64, 128, (2, 2)), (6,
 RPE_CHAIN = os.environ.get("TATT_RPE_CHAIN", "1") != "0"   # 0: one launch per step of the RPE recurrence (A/B runs)
 DEC_FUSED = os.environ.get("TATT_DEC_FUSED", "1") != "0"   # 0: the decoder as one launch per projection / attention / LayerNorm (A/B runs)
 WS_FLOATS = 48 * 1024 * 1024
+RPE_TAIL_SPLIT = os.environ.get("TATT_RPE_TAIL_SPLIT", "1") != "0"   # 0: the whole tail of the RPE chain on the chain's stream (A/B runs)
 RPE_TAIL_ON_SIDE = os.environ.get("TATT_RPE_TAIL_ON_SIDE", "1") != "0"   # 0: the main stream joins the RPE chain before the STN head's backward pass (A/B runs)
 ENC_BWD_FORK = os.environ.get("TATT_ENC_BWD_FORK", "1") != "0"   # 0: the text branch's backward pass on the main stream (A/B runs)
 RPE_FINISH_EARLY = os.environ.get("TATT_RPE_FINISH_EARLY", "1") != "0"   # 0: join the RPE chain after the STN head's backward pass (A/B runs)
@@ -1241,29 +1242,26 @@ class Engine:
                         L.rpe_step_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
                                        dgh_all[0, s + 1] if s + 1 < B else None, dgh_all[0, s], dgi_sum, whhT, s, B, dsg, dsh)
 
-        def rpe_tail():
-            """What follows the chain: its weight gradients, the gradient of the (time-invariant) input and of init_factor."""
-            dxg = self.new(64, 1024)
-            for dd, sfx in enumerate(["", "_reverse"]):
+        def rpe_tail(dirs=(0, 1), dx=True):
+            """What follows the chain: its weight gradients (of the directions `dirs`), and with dx the gradient of the
+            (time-invariant) input and of init_factor."""
+            for dd in dirs:
+                sfx = ["", "_reverse"][dd]
                 self.linear_dw(dgh_all[dd], hstep[dd], G[g + "weight_hh_l0" + sfx], 64 * B, 1536, 512, fp32=True)
                 self.colsum(dgh_all[dd], 64 * B, 1536, G[g + "bias_hh_l0" + sfx])
                 self.linear_dw(dgi_sum[dd], xg, G[g + "weight_ih_l0" + sfx], 64, 1536, 1024, fp32=True)
                 self.colsum(dgi_sum[dd], 64, 1536, G[g + "bias_ih_l0" + sfx])
-                self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd, splitk=8, fp32=True)
-            L.rpe_scatter_dx(dxg, G[ig + "init_factor.weight"], 1)
+            if dx:
+                dxg = self.new(64, 1024)
+                for dd, sfx in enumerate(["", "_reverse"]):
+                    self.linear_dx(dgi_sum[dd], P[g + "weight_ih_l0" + sfx], dxg, 64, 1536, 1024, acc=dd, splitk=8, fp32=True)
+                L.rpe_scatter_dx(dxg, G[ig + "init_factor.weight"], 1)
 
         rpe_on_side = RPE_TAIL_ON_SIDE and owner is None and side != main and self.wgrad_mode == "batch"
+        chain_done = None
         if rpe_on_side:
-            # The chain's tail stays on the chain's own stream, with a workspace of its own and its weight-gradient kernels launched
-            # in place (not through the queue of the weight-gradient streams): it starts the moment the chain ends, and the main
-            # stream -- which used to wait for the chain here before the STN head's backward pass -- joins at the end of the pass.
-            need = max(1536 * 512 * self._splitk(1536, 512, 64 * B), 8 * 64 * 1024, 1 << 20)   # split-K slabs of the W_hh gradient / of dxg
-            if self.ws_side_b is None or self.ws_side_b.device != self.dev or self.ws_side_b.numel() < need:
-                self.ws_side_b = torch.empty(need, device=self.dev)
-            ws_keep, self.ws, self._wgrad_ws = self.ws, self.ws_side_b, self.ws_side_b
-            with torch.cuda.stream(side):
-                rpe_tail()
-            self.ws, self._wgrad_ws = ws_keep, None
+            chain_done = torch.cuda.Event()
+            chain_done.record(side)
 
         def rpe_finish():
             if owner is not None or rpe_on_side:
@@ -1274,14 +1272,20 @@ class Engine:
         def rpe_join():
             if rpe_on_side:
                 main.wait_stream(side)
+                if forked:
+                    main.wait_stream(enc)
         # encoder, per pass (the text branch runs once per pass: its dropout masks differ); the passes' gradients wrt the doubled
         # encoder input (shared) are summed.  Nothing downstream on the image chain reads what this produces (parameter gradients
         # only), so the two dozen small launches run on the text branch's stream beside block1's and the STN head's backward pass,
         # with a workspace of their own; the main stream joins before the weight-gradient queue they fed is flushed.
         enc = self.enc_stream() if ENC_BWD_FORK else main
         enc.wait_stream(main)
-        if self.ws_enc is None or self.ws_enc.device != self.dev:
-            self.ws_enc = torch.empty(1 << 20, device=self.dev)
+        # (sized once, for the RPE tail that may follow on this stream: replacing it later would free memory that kernels of this
+        #  strand still use to the main stream's allocator)
+        need = max(1536 * 512 * self._splitk(1536, 512, 64 * B), 8 * 64 * 1024, 1 << 20)   # split-K slabs of the RPE W_hh gradient / of dxg
+        if self.ws_enc is None or self.ws_enc.device != self.dev or self.ws_enc.numel() < need:
+            torch.cuda.current_stream().wait_stream(enc)      # nothing of an earlier pass may still be using the old one
+            self.ws_enc = torch.empty(need, device=self.dev)
         forked = enc != main
         ws_main, self.ws = self.ws, (self.ws_enc if forked else self.ws)
         self._strand = forked                                 # a guarded write must not join the weight-gradient streams from here
@@ -1314,11 +1318,30 @@ class Engine:
             dt0 = self.new(Rt, 64)
             L.prelu_bwd(t0, P[ig + "activation.weight"], dt, dt0, G[ig + "activation.weight"], 1, Rt * 64, self.ws)
             self.linear_dwb(dt0, tpr, G[ig + "fc_in.weight"], G[ig + "fc_in.bias"], Rt, 64, K)
+            enc_done = torch.cuda.Event()
+            enc_done.record(enc)
         self.ws, self._strand = ws_main, False
+        if rpe_on_side:
+            # The chain's tail stays off the main stream, which used to wait for the chain here before the STN head's backward pass
+            # and now joins at the end of the pass: the input gradient and one direction's weight gradients follow the chain on its
+            # own stream, the other direction's go behind the text branch (a third stream that is idle by then); the weight-gradient
+            # kernels are launched in place, with workspaces of the strands' own, not through the queue of the weight-gradient streams.
+            if self.ws_side_b is None or self.ws_side_b.device != self.dev or self.ws_side_b.numel() < need:
+                self.ws_side_b = torch.empty(need, device=self.dev)   # (first use by this pass: nothing in flight reads an old one)
+            two = forked and RPE_TAIL_SPLIT
+            ws_keep, self.ws, self._wgrad_ws = self.ws, self.ws_side_b, self.ws_side_b
+            with torch.cuda.stream(side):
+                rpe_tail(dirs=(0,) if two else (0, 1))
+            if two:
+                self.ws = self._wgrad_ws = self.ws_enc
+                enc.wait_event(chain_done)
+                with torch.cuda.stream(enc):
+                    rpe_tail(dirs=(1,), dx=False)
+            self.ws, self._wgrad_ws = ws_keep, None
 
-        def enc_join():
+        def enc_join():                                           # the text branch's backward pass (not what may follow it on that stream)
             if forked:
-                main.wait_stream(enc)
+                main.wait_event(enc_done)
 
         # ---- block1 ------------------------------------------------------------------------------------------------
         dc1 = self.new(Ra, 64)
