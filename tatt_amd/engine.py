@@ -25,6 +25,7 @@ STN_STAGES = [(0, 4, 32, (2, 2)), (2, 32, 64, (2, 2)), (4, 64, 128, (2, 2)), (6,
 RPE_CHAIN = os.environ.get("TATT_RPE_CHAIN", "1") != "0"   # 0: one launch per step of the RPE recurrence (A/B runs)
 DEC_FUSED = os.environ.get("TATT_DEC_FUSED", "1") != "0"   # 0: the decoder as one launch per projection / attention / LayerNorm (A/B runs)
 WS_FLOATS = 48 * 1024 * 1024
+RPE_FORK_EARLY = os.environ.get("TATT_RPE_FORK_EARLY", "1") != "0"   # 0: the RPE chain forks after the decoder's reductions (A/B runs)
 RPE_TAIL_SPLIT = os.environ.get("TATT_RPE_TAIL_SPLIT", "1") != "0"   # 0: the whole tail of the RPE chain on the chain's stream (A/B runs)
 RPE_TAIL_ON_SIDE = os.environ.get("TATT_RPE_TAIL_ON_SIDE", "1") != "0"   # 0: the main stream joins the RPE chain before the STN head's backward pass (A/B runs)
 ENC_BWD_FORK = os.environ.get("TATT_ENC_BWD_FORK", "1") != "0"   # 0: the text branch's backward pass on the main stream (A/B runs)
@@ -653,7 +654,7 @@ class Engine:
         fn(layer, dt3_in, dtp, dec_w, dec_kv[layer][2], (VP * 8)(*ptr(self._dec_params(layer))), nw, (VP * 7)(*ptr(saved[layer])), dtgt, dtgt_acc,
            dqp, dqp_acc, (VP * 4)(*ptr(dY)), kvpart, lnpart, B, Lq, npass, (U32 * len(st))(*st), th, sc, sdev)
 
-    def _dec_bwd_fused(self, dec, dtp, db1, dqp, dkins, dmems, kins, mems, B, Lq, cfgs, G):
+    def _dec_bwd_fused(self, dec, dtp, db1, dqp, dkins, dmems, kins, mems, B, Lq, cfgs, G, after_dqp=None):
         """Backward of both decoder layers: two tatt_dec_bwd launches (layer 1, then layer 0 -- which adds its input gradient onto
         db1 and its query_pos gradient onto layer 1's), the reductions of their partials, and ONE grouped launch for the eight
         [64,64] weight gradients.  B: batch elements of all passes; kins / mems / dkins / dmems: per pass (keys = memory + pos)."""
@@ -663,9 +664,8 @@ class Engine:
         R0, Rt, Rg = B * Lq, B * 26, (B // ng) * 26
         VP = ctypes.c_void_p
         dtgt1 = self.new(R0, 64)
-        wg = []
-        for li in (1, 0):
-            d = f"{tr}decoder.layers.{li}."
+        wg, outs = [], {}
+        for li in (1, 0):                                                  # the two launches back to back: layer 0 needs layer 1's dtgt only
             dY = [self.new(R0, 64) for _ in range(4)]
             kvpart, lnpart = self.new(L.dec_bwd_kvpart_floats(B, Lq)), self.new(L.dec_bwd_lnpart_floats(B, Lq))
             if li == 0:
@@ -673,6 +673,12 @@ class Engine:
             self._dec_call(L.dec_bwd, li, None, None, dec_w, dec_kv, saved, None, B, Lq, cfgs,
                            extra=(None if li == 1 else dtgt1, dtp, dtgt1 if li == 1 else db1, 0 if li == 1 else 1, dqp, 0 if li == 1 else 1,
                                   dY, kvpart, lnpart))
+            outs[li] = (dY, kvpart, lnpart)
+        if after_dqp is not None:                                          # dqp is complete: the RPE's BPTT chain -- the longest strand of
+            after_dqp()                                                    # what is left of the pass -- forks here, ahead of the reductions
+        for li in (1, 0):
+            d = f"{tr}decoder.layers.{li}."
+            dY, kvpart, lnpart = outs[li]
             L.dec_ln_final(lnpart, B, Lq, (VP * 6)(*[G[n].data_ptr() for n in (d + "norm2.weight", d + "norm2.bias", d + "norm3.weight", d + "norm3.bias",
                                                                             tr + "decoder.norm.weight", tr + "decoder.norm.bias")]))
             dKp, dVp = self.new(Rt, 64), self.new(Rt, 64)
@@ -1182,10 +1188,51 @@ class Engine:
         dmems, dkins = [self.new(Rt, 64) for _ in range(ng)], [self.new(Rt, 64) for _ in range(ng)]
         dnext = None                                                           # grad flowing into layer li's output from above
         fused = len(dec) > 0 and isinstance(dec[0], str)
-        if fused:
-            self._dec_bwd_fused(dec, dtp, db1, dqp, dkins, dmems, [tx[8] for tx in text], [tx[7] for tx in text], Bt, H * W, cfgs, G)
+        # The recurrent positional encoding's BPTT over the batch axis -- a chain of B latency-bound steps, the longest strand of what is
+        # left of the pass -- runs on the side stream beside the encoder / block1 / STN backward.  What it needs besides dqp (zeroed
+        # carries, W_hh transposed) is made now, ahead of the decoder's backward kernels; the chain itself forks the
+        # moment dqp is complete (start_rpe_chain, called by _dec_bwd_fused between its launches and their reductions).
+        g = tr + "gru_encoding."
+        whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
+        dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
+        main, side = torch.cuda.current_stream(), self.side_stream()
+        owner = ctx.get("rpe_owner")
+        if owner is None:
+            # (on the main stream, ahead of the decoder's kernels: made on the side stream -- one more early fork in the captured graph --
+            #  the step was 0.2 ms slower, whichever point the chain then forked at)
+            carry = self.zeros(2, 64, 512)
+            dgi_sum = self.zeros(2, 64, 1536)
+            dgh_all = self.new(2, B, 64, 1536)
+            whhT = self.new(2, 512, 1536)
+            L.rpe_whh_transpose(whh_f, whh_b, whhT)
+            if self.rpe_chain() and (self._rpe_sync_b is None or self._rpe_sync_b.device != self.dev):
+                self._rpe_sync_b = torch.zeros(L.rpe_chain_sync_words(B), device=self.dev, dtype=torch.int32)
+
+        def start_rpe_chain():
             if ng == 2:                                                        # both passes read the same query_pos
                 axpby(dqp[R0:], 1.0, None, 0.0, dqp, R0 * 64, 1)
+            if owner is not None:                                   # the chain belongs to another pass of this step (forward(rpe_from=...))
+                owner["dqp_extra"] = dqp
+                return
+            if ctx.get("rpe_lent"):                             # gradient handed over by the pass that reused this chain
+                if ctx.get("dqp_extra") is None:
+                    raise RuntimeError("the pass that reused this pass's RPE chain (forward(rpe_from=...)) must run its backward first")
+                axpby(ctx["dqp_extra"], 1.0, None, 0.0, dqp, R0 * 64, 1)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                if self.rpe_chain():   # the whole BPTT chain as one launch of persistent workgroups (tatt_rpe_chain_bwd)
+                    L.rpe_chain_bwd(gi, gh_all, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep, dqp, carry, dgh_all, dgi_sum, whhT,
+                                    B, dsg, dsh, self._rpe_sync_b)
+                else:
+                    for s_ in reversed(range(B)):
+                        L.rpe_step_bwd(gi, gh_all[0, s_], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s_], dqp, carry,
+                                       dgh_all[0, s_ + 1] if s_ + 1 < B else None, dgh_all[0, s_], dgi_sum, whhT, s_, B, dsg, dsh)
+
+        if fused:
+            self._dec_bwd_fused(dec, dtp, db1, dqp, dkins, dmems, [tx[8] for tx in text], [tx[7] for tx in text], Bt, H * W, cfgs, G,
+                                after_dqp=start_rpe_chain if RPE_FORK_EARLY else None)
+            if not RPE_FORK_EARLY:
+                start_rpe_chain()
         kin, mem, dkin, dmem = text[0][8], text[0][7], dkins[0], dmems[0]
         for li in (() if fused else (1, 0)):
             d = f"{tr}decoder.layers.{li}."
@@ -1210,37 +1257,8 @@ class Engine:
             axpby(dkins[q_], 1.0, None, 0.0, dmems[q_], Rt * 64, 1)           # kin = mem + pos
         # (no flush here: the decoder's and the encoder's weight gradients stay queued until rpe_finish() -- bulk kernels beside the
         #  RPE chain slow its 64 latency-bound steps down by more than the overlap returns: 9.51 -> 9.45 ms)
-        # recurrent positional encoding, BPTT over the batch axis: dqp is complete here.  The chain of B latency-bound
-        # launches runs on the side stream beside the encoder / block1 / STN backward; its weight-gradient GEMMs (which
-        # need the shared workspace) follow after the join at the end of the pass.
-        g = tr + "gru_encoding."
-        whh_f, whh_b = P[g + "weight_hh_l0"], P[g + "weight_hh_l0_reverse"]
-        dsh, dsg = (B + 1) * 64 * 512, B * 64 * 1536
-        carry = self.zeros(2, 64, 512)
-        dgi_sum = self.zeros(2, 64, 1536)
-        dgh_all = self.new(2, B, 64, 1536)
-        whhT = self.new(2, 512, 1536)
-        main, side = torch.cuda.current_stream(), self.side_stream()
-        owner = ctx.get("rpe_owner")
-        if owner is not None:                                   # the chain belongs to another pass of this step (forward(rpe_from=...))
-            owner["dqp_extra"] = dqp
-        else:
-            if ctx.get("rpe_lent"):                             # gradient handed over by the pass that reused this chain
-                if ctx.get("dqp_extra") is None:
-                    raise RuntimeError("the pass that reused this pass's RPE chain (forward(rpe_from=...)) must run its backward first")
-                axpby(ctx["dqp_extra"], 1.0, None, 0.0, dqp, R0 * 64, 1)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                L.rpe_whh_transpose(whh_f, whh_b, whhT)
-                if self.rpe_chain():   # the whole BPTT chain as one launch of persistent workgroups (tatt_rpe_chain_bwd)
-                    if self._rpe_sync_b is None or self._rpe_sync_b.device != self.dev:
-                        self._rpe_sync_b = torch.zeros(L.rpe_chain_sync_words(B), device=self.dev, dtype=torch.int32)
-                    L.rpe_chain_bwd(gi, gh_all, P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep, dqp, carry, dgh_all, dgi_sum, whhT,
-                                    B, dsg, dsh, self._rpe_sync_b)
-                else:
-                    for s in reversed(range(B)):
-                        L.rpe_step_bwd(gi, gh_all[0, s], P[g + "bias_hh_l0"], P[g + "bias_hh_l0_reverse"], hstep[0, s], dqp, carry,
-                                       dgh_all[0, s + 1] if s + 1 < B else None, dgh_all[0, s], dgi_sum, whhT, s, B, dsg, dsh)
+        if not fused:
+            start_rpe_chain()
 
         def rpe_tail(dirs=(0, 1), dx=True):
             """What follows the chain: its weight gradients (of the directions `dirs`), and with dx the gradient of the
