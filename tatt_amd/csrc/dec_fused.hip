@@ -102,7 +102,15 @@ __device__ __forceinline__ void mm64(T32& acc, const float4* __restrict__ Wf, in
       acc.b[1] = mfma(a1.w, x.b[obk][g * 4 + 3], acc.b[1]);
     }
 }
-__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+// lane l <-> lane l ^ 32 (the two halves of a token's features) on v_permlane32_swap (VALU; no trip through the LDS crossbar)
+__device__ __forceinline__ float pair_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pair_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 
 __device__ __forceinline__ void ln_stats(const T32& v, float& mean, float& rstd) {
   float s = 0.f;
@@ -161,7 +169,7 @@ __device__ __forceinline__ void head_probs(f32x16& p, const T32& Q, const float4
 #pragma unroll
   for (int i = 1; i < 12; ++i) mx = fmaxf(mx, s[i]);
   if (hi == 0) mx = fmaxf(mx, fmaxf(s[12], s[13]));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  mx = pair_max(mx);
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
