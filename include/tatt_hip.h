@@ -27,6 +27,8 @@ typedef void* hipStream_t;
 #define TATT_ACCUMULATE 1
 #define TATT_BF16 2
 #define TATT_F32X3 4
+#define TATT_X_BF16 8
+#define TATT_DY_BF16 16
 
 #ifdef __cplusplus
 extern "C" {
@@ -43,7 +45,7 @@ int tatt_version(void);
  *     TATT_BF16 (2)        operands rounded to bf16 (nearest-even) on their way into v_mfma_f32_32x32x16_bf16, fp32 accumulation
  *                          (BASELINE.json config 3; the reference itself has no autocast).  Default = exact fp32 operands on
  *                          v_mfma_f32_32x32x2_f32, the parity path.  Launches whose shapes take the generic (non-FAST) loaders
- *                          stay fp32 either way; tensors in memory are fp32 in both modes.
+ *                          stay fp32 either way; tensors in memory are fp32 unless TATT_X_BF16 / TATT_DY_BF16 say otherwise.
  *     TATT_F32X3 (4)       opt-in: fp32 products on the bf16 matrix core.  Every operand element is split exactly into three
  *                          bf16 pieces (3 x 8 significant bits) on its way into LDS and a*b is accumulated in fp32 as six
  *                          v_mfma_f32_32x32x16_bf16 terms (a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0; what is dropped is below the
@@ -51,6 +53,15 @@ int tatt_version(void);
  *                          3x3 64->64 convolution 34 us instead of 49.  Only launches with k-contiguous operands (NT GEMMs, implicit-GEMM
  *                          convolution forward / dgrad) have such a kernel; any other launch carrying the flag runs on fp32 MFMA.
  *                          TATT_BF16 wins if both bits are set.
+ *     TATT_X_BF16 (8)      tatt_conv_fwd* / tatt_conv_fwd_bn / tatt_conv_wgrad, together with TATT_BF16: X points at bf16 elements
+ *     TATT_DY_BF16 (16)    tatt_conv_wgrad, together with TATT_BF16: dY points at bf16 elements.
+ *                          bf16 STORAGE (BASELINE.json config 3 "bf16"): in the bf16 step every tensor whose only
+ *                          readers are bf16 matrix-core launches -- mish(BN(conv1)) of each SRB, block7's output + skip, and the
+ *                          gradients arriving at the 3x3 convolutions' outputs -- is written once as bf16 by its producer
+ *                          (tatt_bn_apply_bf16, tatt_bn_bwd_from_partial_bf16, tatt_pixshuf_mish_bwd_bf16) and read as bf16: the same
+ *                          numbers the launch would have rounded to, half the bytes.  ldx / lddy stay in elements; supported: the
+ *                          convolution input (Cin % 32 == 0, packed weights), weight gradients of more than 16 output channels with
+ *                          dY, or X and dY, in bf16 (refused with TATT_ERR_ARG otherwise).
  * Replaces F.linear at
  * model/tsrn.py:213, :1083 (1x1 conv), model/transformer_v2.py:476,:480,:819,:829 (MHA in/out proj, FFN),
  * nn.GRU input projections (model/tsrn.py:1088, model/transformer_v2.py:218), stn_head.py:99-100. */
@@ -116,6 +127,8 @@ size_t tatt_bn_workspace(int C);
 int tatt_bn_stats(const float* x, long ldx, int R, int C, float eps, float momentum, float* stat, float* run_mean, float* run_var, float* workspace, hipStream_t stream);
 int tatt_bn_stat_from_running(const float* rm, const float* rv, int C, float eps, float* stat, hipStream_t stream);
 int tatt_bn_apply(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr, float* y, long ldy, int R, int C, int act, hipStream_t stream);
+/* tatt_bn_apply with y stored as bf16 (round to nearest even; ldy in elements; y 8-byte aligned) -- see TATT_X_BF16 */
+int tatt_bn_apply_bf16(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr, uint16_t* y, long ldy, int R, int C, int act, hipStream_t stream);
 int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const float* stat, const float* gamma, const float* beta, float* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int act, int train, int accumulate_params, int accumulate_dx, float* workspace, hipStream_t stream);
 
 /* BatchNorm fused into the producing GEMM / convolution (model/tsrn.py:868-877 conv-BN pairs and their autograd): the first half of
@@ -130,6 +143,8 @@ int tatt_conv_fwd_bn(const float* X, const float* Wt, const float* bias, float* 
 int tatt_gemm_cat_bnbwd(const float* A, const float* A2, int ksplit, const float* B, float* C, float* C2, int nsplit, const float* bias, int M, int N, int K, long sam, long sbn, long sbk, long ldc, long ldc2, int accumulate, int accumulate2, int flags, const float* bn_x, long bn_ldx, const float* bn_stat, const float* bn_gamma, const float* bn_beta, int bn_act, int bn_C, float* partial, hipStream_t stream);
 int tatt_bn_stats_from_partial(const float* partial, int nblk, int rows_per_blk, int R, int C, float eps, float momentum, float* stat, float* run_mean, float* run_var, hipStream_t stream);
 int tatt_bn_bwd_from_partial(const float* x, long ldx, const float* g, long ldg, const float* stat, const float* gamma, const float* beta, const float* partial, int nblk, float* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int train, int accumulate_params, int accumulate_dx, float* sums, hipStream_t stream);
+/* the same with dx stored as bf16 (no accumulation onto dx): the gradient that only the convolution's dgrad / wgrad launches read */
+int tatt_bn_bwd_from_partial_bf16(const float* x, long ldx, const float* g, long ldg, const float* stat, const float* gamma, const float* beta, const float* partial, int nblk, uint16_t* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int train, int accumulate_params, float* sums, hipStream_t stream);
 
 /* ---- LayerNorm(64) with fused residual + dropout (model/transformer_v2.py:478-482, :827-831, :380) -------- */
 int tatt_ln_fwd(const float* x, const float* res, uint32_t seed_site, uint32_t thresh, float scale, const uint32_t* seed_dev, const float* gamma, const float* beta, float* vout, float* y, int rows, float eps, hipStream_t stream);
@@ -229,6 +244,11 @@ size_t tatt_colsum_workspace(int C);
 int tatt_colsum(const float* x, long ld, int R, int C, float* out, int accumulate, float* workspace, hipStream_t stream);
 int tatt_pixshuf_mish_fwd(const float* x, float* y, int B, int H, int W, int C, hipStream_t stream);
 int tatt_pixshuf_mish_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, hipStream_t stream);
+/* dx stored as bf16: the gradient of the up-sampling convolution's output, read by that convolution's dgrad / wgrad launches only (C = 64).
+ * colpart (may be NULL): [tatt_pixshuf_colpart_rows(B, H, W)][4C] fp32 column sums of the UNROUNDED values, one row per 64 pixels --
+ * tatt_colsum over it is the convolution's bias gradient, as exact as from an fp32-stored dx. */
+size_t tatt_pixshuf_colpart_rows(int B, int H, int W);
+int tatt_pixshuf_mish_bwd_bf16(const float* x, const float* dy, uint16_t* dx, float* colpart, int B, int H, int W, int C, hipStream_t stream);
 int tatt_sigmoid_to_nchw(const float* pre, float* sr, int B, int C, int HW, hipStream_t stream);
 int tatt_sigmoid_bwd_to_nhwc(const float* sr, const float* dsr, float* dpre, int B, int C, int HW, hipStream_t stream);
 int tatt_maxpool_fwd(const float* x, float* y, int B, int H, int W, int C, int kh, int kw, hipStream_t stream);

@@ -14,6 +14,8 @@
 #define TATT_ACCUMULATE 1  // tatt_conv_wgrad, tatt_conv_skinny_fwd: add to the destination
 #define TATT_F32X3 4       // fp32 products from three bf16 pieces per operand (six v_mfma_f32_32x32x16_bf16 terms, fp32 accumulate); TATT_BF16 wins if both are set
 #define TATT_BF16 2        // operands rounded to bf16 (nearest-even) into v_mfma_f32_32x32x16_bf16, fp32 accumulate
+#define TATT_X_BF16 8      // convolution entry points, with TATT_BF16: the input X (tatt_conv_wgrad: X) is STORED as bf16 (pointer to 2-byte elements)
+#define TATT_DY_BF16 16    // tatt_conv_wgrad, with TATT_BF16: dY is stored as bf16
 
 void tatt_set_error(const char* fmt, ...);
 
@@ -118,6 +120,15 @@ __device__ __forceinline__ float block16_colsum(const float* __restrict__ partia
     for (int j = 0; j < 16; ++j) t += red[j * 16 + cl];
   __syncthreads();
   return t;
+}
+
+// four fp32 values -> four bf16 (round to nearest even), 8 bytes: the store of a tensor that is kept in bf16 (bf16 step, see engine.py)
+__device__ __forceinline__ uint2 tatt_pack_bf16x4(float a, float b, float c, float d) {
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ lo = {a, b}, hi = {c, d};
+  const bf16x2_ l = __builtin_convertvector(lo, bf16x2_), h = __builtin_convertvector(hi, bf16x2_);
+  return make_uint2(*reinterpret_cast<const unsigned*>(&l), *reinterpret_cast<const unsigned*>(&h));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

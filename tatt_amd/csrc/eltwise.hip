@@ -194,6 +194,43 @@ __global__ __launch_bounds__(256) void pixshuf_mish_bwd_k(const float* __restric
   reinterpret_cast<float4*>(dx)[i] = make_float4(g0 * mish_gradf_(v.x), g1 * mish_gradf_(v.y), g2 * mish_gradf_(v.z), g3 * mish_gradf_(v.w));
 }
 
+// The same with dx STORED AS bf16 (the bf16 step: this gradient is read by the up-sampling convolution's dgrad / wgrad launches only,
+// which round it to bf16 anyway) and, because the convolution's bias gradient is the column sum of the UNROUNDED values, per-block
+// column sums in fp32 on the side: colpart [gridDim.x][4C] (NULL: none; tatt_colsum over it gives the bias gradient).  C = 64: a
+// thread keeps one channel quad and walks PSB_PIX / 4 pixels.
+constexpr int PSB_PIX = 64;
+__global__ __launch_bounds__(256) void pixshuf_mish_bwd16_k(const float* __restrict__ x, const float* __restrict__ dy, uint2* __restrict__ dx,
+                                                            float* __restrict__ colpart, int H, int W, long npix) {
+  constexpr int C = 64;
+  __shared__ float4 red[4][C];
+  const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int it = 0; it < PSB_PIX / 4; ++it) {
+    const long p = (long)blockIdx.x * PSB_PIX + it * 4 + pl;
+    if (p >= npix) break;
+    const int xx = (int)(p % W);
+    const long q = p / W;
+    const int yy = (int)(q % H);
+    const long b = q / H;
+    const long i = p * C + c;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float* g = dy + ((b * 2 * H + 2 * yy) * 2 * W + 2 * xx) * C + c;
+    const float g0 = g[0], g1 = g[C], g2 = g[(long)2 * W * C], g3 = g[(long)2 * W * C + C];
+    const float o0 = g0 * mish_gradf_(v.x), o1 = g1 * mish_gradf_(v.y), o2 = g2 * mish_gradf_(v.z), o3 = g3 * mish_gradf_(v.w);
+    dx[i] = tatt_pack_bf16x4(o0, o1, o2, o3);
+    acc.x += o0; acc.y += o1; acc.z += o2; acc.w += o3;
+  }
+  if (!colpart) return;
+  red[pl][c] = acc;
+  __syncthreads();
+  if (pl == 0) {
+    const float4 a = red[0][c], b2 = red[1][c], c2 = red[2][c], d2 = red[3][c];
+    reinterpret_cast<float4*>(colpart + (long)blockIdx.x * 4 * C)[c] =
+        make_float4((a.x + b2.x) + (c2.x + d2.x), (a.y + b2.y) + (c2.y + d2.y), (a.z + b2.z) + (c2.z + d2.z), (a.w + b2.w) + (c2.w + d2.w));
+  }
+}
+
 // sr (NCHW) = sigmoid(pre NHWC [P,C])
 __global__ void sigmoid_to_nchw_k(const float* __restrict__ pre, float* __restrict__ sr, int B, int C, int HW) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -379,6 +416,17 @@ int tatt_pixshuf_mish_bwd(const float* x, const float* dy, float* dx, int B, int
   TATT_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)dx)) & 15) == 0, "tatt_pixshuf_mish_bwd: x and dx must be 16-byte aligned");
   hipLaunchKernelGGL(pixshuf_mish_bwd_k, GRID1D((long)B * H * W * C), 0, st, x, dy, dx, B, H, W, C);
   TATT_LAUNCH_CHECK("pixshuf_mish_bwd");
+  return TATT_OK;
+}
+// tatt_pixshuf_mish_bwd with dx stored as bf16; colpart (optional): tatt_pixshuf_colpart_rows(B, H, W) x 4C fp32 column sums of the
+// unrounded values, one row per block of 64 pixels
+size_t tatt_pixshuf_colpart_rows(int B, int H, int W) { return (size_t)cdiv((long)B * H * W, PSB_PIX); }
+int tatt_pixshuf_mish_bwd_bf16(const float* x, const float* dy, uint16_t* dx, float* colpart, int B, int H, int W, int C, hipStream_t st) {
+  TATT_CHECK_ARG(C == 64 && B > 0 && H > 0 && W > 0, "tatt_pixshuf_mish_bwd_bf16: built for C = 64 (got %d)", C);
+  TATT_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)dx) & 7) == 0 && (((uintptr_t)colpart) & 15) == 0, "tatt_pixshuf_mish_bwd_bf16: x / colpart 16-byte, dx 8-byte aligned");
+  const long npix = (long)B * H * W;
+  hipLaunchKernelGGL(pixshuf_mish_bwd16_k, dim3(cdiv(npix, PSB_PIX)), dim3(256), 0, st, x, dy, reinterpret_cast<uint2*>(dx), colpart, H, W, npix);
+  TATT_LAUNCH_CHECK("pixshuf_mish_bwd<bf16 out>");
   return TATT_OK;
 }
 int tatt_sigmoid_to_nchw(const float* pre, float* sr, int B, int C, int HW, hipStream_t st) {

@@ -57,6 +57,7 @@ struct GemmArgs {
   long epi_ldx;
   const float *epi_stat, *epi_gamma, *epi_beta;  // EPI 2: stat [2][epi_C] (mean, invstd)
   int epi_act, epi_C;
+  int a16, b16;   // host only: the A / B operand is STORED as bf16 (bf16 precision only; offsets in elements as ever)
   int bf16;       // host only, precision of the products: 0 fp32 MFMA, 1 operands rounded to bf16 (TATT_BF16), 2 three bf16 pieces per operand (TATT_F32X3)
   ConvGeom g;     // for OP_IM2COL / OP_CONVW / OP_IM2COL_N
   long w_sn, w_sci, w_stap, w_base;  // OP_CONVW: W[n*w_sn + ci*w_sci + w_base + tap*w_stap]
@@ -90,6 +91,26 @@ __device__ __forceinline__ float4 bload4s(__amdgpu_buffer_rsrc_t r, int voff, in
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, int byte_off, bool ok) {
   i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? byte_off : BUF_OOB, 0, 0);
   return *reinterpret_cast<float4*>(&v);
+}
+
+// Operands STORED as bf16 (flags TATT_X_BF16 / TATT_DY_BF16 of the convolution entry points: the bf16 step keeps the tensors whose
+// every reader is a bf16 matrix-core launch in bf16): four consecutive elements are one 8-byte load, widened to fp32 in registers --
+// exact, and the LDS staging below rounds them back to the same bf16 values -- so only the loaders' byte offsets (element size ES)
+// and the load instruction differ from the fp32-stored form.
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 widen_bf16x4(i32x2 v) {
+  return make_float4(__uint_as_float((unsigned)v.x << 16), __uint_as_float((unsigned)v.x & 0xffff0000u), __uint_as_float((unsigned)v.y << 16),
+                     __uint_as_float((unsigned)v.y & 0xffff0000u));
+}
+template <bool H16>
+__device__ __forceinline__ float4 bload4s_t(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  if constexpr (H16) return widen_bf16x4(__builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+  else return bload4s(r, voff, soff);
+}
+template <bool H16>
+__device__ __forceinline__ float4 bload4_t(__amdgpu_buffer_rsrc_t r, int byte_off, bool ok) {
+  if constexpr (H16) return widen_bf16x4(__builtin_amdgcn_raw_buffer_load_b64(r, ok ? byte_off : BUF_OOB, 0, 0));
+  else return bload4(r, byte_off, ok);
 }
 
 // (tap, ci, dy, dx) of k = k0 + off, k = tap*Cin + ci.  When a K tile never straddles a tap (Cin % BK == 0) everything but
@@ -200,8 +221,12 @@ constexpr int X3_BUF = 3 * (X3_A_PLANE + X3_B_PLANE);                 // bytes o
 constexpr int HALO_Q = 4 * 66;            // halo pixels of a 2 x 64 pixel tile
 constexpr int HALO_PLANE = HALO_Q * 64;   // bytes of one bf16 plane (32 channels)
 
-template <int AOP, int BOP, bool FAST, bool BF16, bool TAP9, int EPI, bool X3, bool HALO = false>
+template <int AOP, int BOP, bool FAST, bool BF16, bool TAP9, int EPI, bool X3, bool HALO = false, bool A16 = false, bool B16 = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
+  static_assert(!(A16 || B16) || (FAST && BF16), "bf16-stored operands feed the bf16 matrix-core launches (FAST loaders) only");
+  static_assert(!A16 || AOP == OP_IM2COL || AOP == OP_IM2COL_M || AOP == OP_ROWCONTIG, "bf16-stored A: activations / gradients, not weights");
+  static_assert(!B16 || BOP == OP_ROWCONTIG || BOP == OP_IM2COL_N, "bf16-stored B: activations / gradients, not weights");
+  constexpr int ESA = A16 ? 2 : 4, ESB = B16 ? 2 : 4;  // bytes per stored element of the operands
   static_assert(!HALO || (TAP9 && (BF16 || X3)), "HALO is a variant of the TAP9 launches in bf16 / split-product precision");
   static_assert(FAST || !BF16, "the bf16 path exists for the FAST loaders only");
   static_assert(!TAP9 || (FAST && AOP == OP_IM2COL && BOP == OP_CONVW_P), "TAP9 is the 3x3 Cin=64 im2col specialisation");
@@ -241,7 +266,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
       int y = rem / a.g.W, x = rem - y * a.g.W;
       a_py[j] = m < a.M ? y : -(1 << 20);  // rows past M fail every bounds test
       a_px[j] = x;
-      a_off[j] = m < a.M ? m * a.g.ldx * 4 : 0;
+      a_off[j] = m < a.M ? m * a.g.ldx * ESA : 0;
     }
   }
   int bw_off = 0;  // packed OP_CONVW: byte offset of (n, tap 0, ci 0)
@@ -265,7 +290,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
     bn_ci = n - tap * a.g.Cin;
     bn_tap_dy = tap / a.g.KW - a.g.padH;
     bn_tap_dx = tap % a.g.KW - a.g.padW;
-    bn_off = ((bn_tap_dy * a.g.W + bn_tap_dx) * a.g.ldx + bn_ci) * 4;
+    bn_off = ((bn_tap_dy * a.g.W + bn_tap_dx) * a.g.ldx + bn_ci) * ESB;
   }
 
   // OP_IM2COL_M (wgrad A operand when Cout is tiny): m = (tap, ci) fixed per thread, row(m)-contiguous image
@@ -278,7 +303,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
     am_ci = m - tap * a.g.Cin;
     am_tap_dy = tap / a.g.KW - a.g.padH;
     am_tap_dx = tap % a.g.KW - a.g.padW;
-    am_off = ((am_tap_dy * a.g.W + am_tap_dx) * a.g.ldx + am_ci) * 4;
+    am_off = ((am_tap_dy * a.g.W + am_tap_dx) * a.g.ldx + am_ci) * ESA;
   }
 
   // ---- FAST loader state: constant per-thread byte offsets ----------------------------------------
@@ -293,13 +318,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
       } else if constexpr (AOP == OP_ROWCONTIG) {
         const int m = m0 + (tid & 31) * 4;
         fa_k[j] = X3 ? 2 * (tid >> 5) + j : (tid >> 5) + 16 * j;  // X3: a thread holds (k, k + 1) of its four rows -- the bf16 pairs
-        if (m < a.M) fa_vo[j] = (int)(((long)fa_k[j] * a.sak + m) * 4);
+        if (m < a.M) fa_vo[j] = (int)(((long)fa_k[j] * a.sak + m) * ESA);
       } else if constexpr (AOP == OP_IM2COL) {
-        fa_vo[j] = a_off[j] + kq * 16;
+        fa_vo[j] = a_off[j] + kq * 4 * ESA;
       } else {  // OP_IM2COL_M
         fa_k[j] = X3 ? 2 * (tid >> 5) + j : (tid >> 5) + 16 * j;
         fa_x[j] = fa_k[j] + am_tap_dx;
-        fa_vo[j] = am_off + fa_k[j] * a.g.ldx * 4;
+        fa_vo[j] = am_off + fa_k[j] * a.g.ldx * ESA;
       }
     }
     if constexpr (BOP == OP_STRIDED) {
@@ -308,13 +333,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
     } else if constexpr (BOP == OP_ROWCONTIG) {
       const int n = n0 + (tid & 15) * 4;
       fb_k = tid >> 4;
-      if (n < a.N) fb_vo = (int)(((long)fb_k * a.sbk + n) * 4);
+      if (n < a.N) fb_vo = (int)(((long)fb_k * a.sbk + n) * ESB);
     } else if constexpr (BOP == OP_CONVW_P) {
       if (bw_ok) fb_vo = bw_off + kq * 16;
     } else if constexpr (BOP == OP_IM2COL_N) {
       fb_k = tid >> 4;
       fb_x = fb_k + bn_tap_dx;
-      fb_vo = bn_off + fb_k * a.g.ldx * 4;
+      fb_vo = bn_off + fb_k * a.g.ldx * ESB;
     }
   }
 
@@ -352,39 +377,39 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) ra[j] = bload4s(rs, p ? fa_vo[j] : BUF_OOB, so);
       } else if constexpr (AOP == OP_ROWCONTIG) {
-        const int so = k0u * (int)a.sak * 4;
+        const int so = k0u * (int)a.sak * ESA;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ra[j] = bload4s(rsrcA, fa_k[j] < lim ? fa_vo[j] : BUF_OOB, so);
+        for (int j = 0; j < 2; ++j) ra[j] = bload4s_t<A16>(rsrcA, fa_k[j] < lim ? fa_vo[j] : BUF_OOB, so);
       } else if constexpr (AOP == OP_IM2COL) {  // Cin % BK == 0: the whole tile shares one tap
         const int dy = t_ty - a.g.padH, dx = t_tx - a.g.padW;
-        const int delta = ((dy * a.g.W + dx) * a.g.ldx + t_ci0) * 4;
+        const int delta = ((dy * a.g.W + dx) * a.g.ldx + t_ci0) * ESA;
         const bool live = lim > 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const bool ok = live && (unsigned)(a_py[j] + dy) < (unsigned)a.g.H && (unsigned)(a_px[j] + dx) < (unsigned)a.g.W;
-          ra[j] = bload4s(rsrcA, ok ? fa_vo[j] + delta : BUF_OOB, 0);
+          ra[j] = bload4s_t<A16>(rsrcA, ok ? fa_vo[j] + delta : BUF_OOB, 0);
         }
       } else {  // OP_IM2COL_M, W % BK == 0: the tile's 32 pixels share one image row
         const int y = t_y, x0 = t_x0;
-        const int spix = k0u * a.g.ldx * 4;
+        const int spix = k0u * a.g.ldx * ESA;
         const bool yok = am_ok && (unsigned)(y + am_tap_dy) < (unsigned)a.g.H;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const bool ok = yok && fa_k[j] < lim && (unsigned)(x0 + fa_x[j]) < (unsigned)a.g.W;
-          ra[j] = bload4s(rsrcA, ok ? fa_vo[j] + spix : BUF_OOB, 0);
+          ra[j] = bload4s_t<A16>(rsrcA, ok ? fa_vo[j] + spix : BUF_OOB, 0);
         }
       }
       // ---- B ----
       if constexpr (BOP == OP_STRIDED) {
         rb = bload4s(rsrcB, fb_k < lim ? fb_vo : BUF_OOB, k0u * 4);
       } else if constexpr (BOP == OP_ROWCONTIG) {
-        rb = bload4s(rsrcB, fb_k < lim ? fb_vo : BUF_OOB, k0u * (int)a.sbk * 4);
+        rb = bload4s_t<B16>(rsrcB, fb_k < lim ? fb_vo : BUF_OOB, k0u * (int)a.sbk * ESB);
       } else if constexpr (BOP == OP_CONVW_P) {
         rb = bload4s(rsrcB, lim > 0 ? fb_vo : BUF_OOB, (t_tap * (int)a.w_stap + t_ci0) * 4);
       } else {  // OP_IM2COL_N
         const int y = t_y, x0 = t_x0;
         const bool ok = bn_ok && fb_k < lim && (unsigned)(y + bn_tap_dy) < (unsigned)a.g.H && (unsigned)(x0 + fb_x) < (unsigned)a.g.W;
-        rb = bload4s(rsrcB, ok ? fb_vo + k0u * a.g.ldx * 4 : BUF_OOB, 0);
+        rb = bload4s_t<B16>(rsrcB, ok ? fb_vo + k0u * a.g.ldx * ESB : BUF_OOB, 0);
       }
       // ---- advance to the next tile ----
       t_k0 += BK;
@@ -674,7 +699,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
         const int q = r0 + 64 * it, hy = q / 66, hx = q - hy * 66;
         const int y = y0 - 1 + hy, x = hx - 1;
         const bool ok = q < HALO_Q && (unsigned)y < (unsigned)a.g.H && (unsigned)x < (unsigned)a.g.W;
-        hreg[it] = bload4(rsrcA, (((bimg * a.g.H + y) * a.g.W + x) * a.g.ldx + half * 32 + kq * 4) * 4, ok);
+        hreg[it] = bload4_t<A16>(rsrcA, (((bimg * a.g.H + y) * a.g.W + x) * a.g.ldx + half * 32 + kq * 4) * ESA, ok);
       }
     };
     auto halo_store = [&]() {
@@ -766,7 +791,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-      const int delta = ((dy * a.g.W + dx) * a.g.ldx) * 4;
+      const int delta = ((dy * a.g.W + dx) * a.g.ldx) * ESA;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const bool ok = (unsigned)(a_py[j] + dy) < (unsigned)a.g.H && (unsigned)(a_px[j] + dx) < (unsigned)a.g.W;
@@ -777,7 +802,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
       if (tile >= 18) return;
       const int tap = tile >> 1, half = tile & 1;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) ra[j] = bload4s(rsrcA, va[tap][j], half * (BK * 4));
+      for (int j = 0; j < 2; ++j) ra[j] = bload4s_t<A16>(rsrcA, va[tap][j], half * (BK * ESA));
       rb = bload4s(rsrcB, fb_vo, (tap * 64 + half * BK) * 4);
     };
     load_tap(0, ra0, rb0);
@@ -950,9 +975,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
   }
 }
 
-template <int AOP, int BOP, bool FAST, bool BF16 = false, bool TAP9 = false, int EPI = 0>
+template <int AOP, int BOP, bool FAST, bool BF16 = false, bool TAP9 = false, int EPI = 0, bool A16 = false, bool B16 = false>
 __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs a) {
-  gemm_body<AOP, BOP, FAST, BF16, TAP9, EPI, false>(a);
+  gemm_body<AOP, BOP, FAST, BF16, TAP9, EPI, false, false, A16, B16>(a);
 }
 // the same launches with fp32 products made of three bf16 pieces per operand (flag TATT_F32X3, see gemm_body)
 // (second launch-bound argument = waves per SIMD in HIP: four, i.e. two workgroups per CU and at most 128 registers -- with "2" one
@@ -962,9 +987,9 @@ __global__ __launch_bounds__(NTHR, 4) void gemm_x3_kernel(GemmArgs a) {
   gemm_body<AOP, BOP, true, false, TAP9, EPI, true>(a);
 }
 // TAP9 launches on 64-wide maps in bf16 (X3 = false) or split-product (X3 = true) precision with the input halo resident in LDS
-template <int AOP, int BOP, int EPI, bool X3>
+template <int AOP, int BOP, int EPI, bool X3, bool A16 = false>
 __global__ __launch_bounds__(NTHR, 2) void gemm_halo_kernel(GemmArgs a) {
-  gemm_body<AOP, BOP, true, !X3, true, EPI, X3, true>(a);
+  gemm_body<AOP, BOP, true, !X3, true, EPI, X3, true, A16>(a);
 }
 const int g_halo = [] { const char* e = getenv("TATT_CONV_HALO"); return (e && e[0] == '0') ? 0 : 1; }();  // =0: per-tap loads (A/B runs)
 inline bool halo_ok(const GemmArgs& a) {
@@ -1290,9 +1315,44 @@ bool fast_ok(const GemmArgs& a) {
 
 const int g_tap9 = [] { const char* e = getenv("TATT_CONV_TAP9"); return (e && e[0] == '0') ? 0 : 1; }();  // =0: generic loop (A/B runs)
 
+// launches whose activation / gradient operands are STORED as bf16 (GemmArgs::a16 / b16): the bf16 step's trunk convolutions
+template <int AOP, int BOP, int EPI>
+int launch16(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  if (a.bf16 != 1 || !fast_ok<AOP, BOP>(a)) {
+    tatt_set_error("bf16-stored operands (TATT_X_BF16 / TATT_DY_BF16) need TATT_BF16 precision and 16-byte granular operand layouts");
+    return TATT_ERR_ARG;
+  }
+  if constexpr (AOP == OP_IM2COL && BOP == OP_CONVW_P) {
+    if (a.a16 && !a.b16) {
+      const bool tap9 = g_tap9 && a.g.Cin == 64 && a.g.KH == 3 && a.g.KW == 3 && a.splitk == 1 && a.K == 576 && a.w_stap == 64;
+      if (tap9 && halo_ok(a)) hipLaunchKernelGGL((gemm_halo_kernel<AOP, BOP, EPI, false, true>), grid, dim3(NTHR), 0, st, a);
+      else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, false, EPI, true, false>), grid, dim3(NTHR), 0, st, a);
+      TATT_LAUNCH_CHECK("gemm kernel <bf16-stored input>");
+      return TATT_OK;
+    }
+  } else if constexpr (AOP == OP_IM2COL_M && BOP == OP_ROWCONTIG && EPI == 0) {
+    if (a.b16) {  // weight gradient, (tap, ci) on M: A = X (fp32 or bf16), B = dY (bf16)
+      if (a.a16) hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, false, 0, true, true>), grid, dim3(NTHR), 0, st, a);
+      else hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, false, 0, false, true>), grid, dim3(NTHR), 0, st, a);
+      TATT_LAUNCH_CHECK("gemm kernel <bf16-stored wgrad operands>");
+      return TATT_OK;
+    }
+  } else if constexpr (AOP == OP_ROWCONTIG && BOP == OP_IM2COL_N && EPI == 0) {
+    if (a.a16 && a.b16) {  // weight gradient, Cout on M: A = dY, B = X
+      hipLaunchKernelGGL((gemm_kernel<AOP, BOP, true, true, false, 0, true, true>), grid, dim3(NTHR), 0, st, a);
+      TATT_LAUNCH_CHECK("gemm kernel <bf16-stored wgrad operands>");
+      return TATT_OK;
+    }
+  }
+  tatt_set_error("no kernel for this combination of bf16-stored operands (supported: convolution input; weight gradient with dY, or X and dY, "
+                 "stored as bf16 and more than 16 output channels)");
+  return TATT_ERR_ARG;
+}
+
 template <int AOP, int BOP>
 int launch(const GemmArgs& a, int batch, hipStream_t st) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch * a.splitk);
+  if (a.a16 || a.b16) return launch16<AOP, BOP, 0>(a, grid, st);
   if constexpr (AOP == OP_IM2COL && BOP == OP_CONVW_P) {  // 3x3, Cin = 64, packed weights, whole K in one pass: tap-unrolled loop
     if (g_tap9 && fast_ok<AOP, BOP>(a) && a.g.Cin == 64 && a.g.KH == 3 && a.g.KW == 3 && a.splitk == 1 && a.K == 576 && a.w_stap == 64) {
       if (halo_ok(a)) {
@@ -1448,6 +1508,7 @@ int launch_epi(const GemmArgs& a, hipStream_t st) {
     return TATT_ERR_ARG;
   }
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), 1);
+  if (a.a16 || a.b16) return launch16<AOP, BOP, EPI>(a, grid, st);
   if constexpr (AOP == OP_IM2COL && BOP == OP_CONVW_P) {
     if (g_tap9 && a.g.Cin == 64 && a.g.KH == 3 && a.g.KW == 3 && a.K == 576 && a.w_stap == 64) {
       if (halo_ok(a)) {
@@ -1632,6 +1693,7 @@ int tatt_conv_fwd_splitk(const float* X, const float* Wt, const float* bias, flo
   a.splitk = splitk;
   a.kchunk = cdiv(cdiv(a.K, splitk), BK) * BK;
   a.accumulate = accumulate; a.relu = relu; a.bf16 = prec_of(flags);
+  a.a16 = (flags & TATT_X_BF16) != 0;
   a.g = ConvGeom{H, W, Cin, KH, KW, KH / 2, KW / 2, (int)ldx};
   a.w_sn = w_sn; a.w_sci = w_sci; a.w_base = w_base; a.w_stap = w_stap;
   if (splitk > 1) {
@@ -1670,6 +1732,7 @@ int tatt_conv_fwd_bn(const float* X, const float* Wt, const float* bias, float* 
   a.splitk = 1;
   a.kchunk = cdiv(a.K, BK) * BK;
   a.bf16 = prec_of(flags);
+  a.a16 = (flags & TATT_X_BF16) != 0;
   a.g = ConvGeom{H, W, Cin, KH, KW, KH / 2, KW / 2, (int)ldx};
   a.w_sn = w_sn; a.w_sci = w_sci; a.w_base = w_base; a.w_stap = w_stap;
   a.epi_partial = partial; a.epi_C = Cout;
@@ -1755,6 +1818,9 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
   a.kchunk = cdiv(cdiv(a.K, splitk), BK) * BK;
   a.bf16 = prec_of(flags);
   a.g = ConvGeom{H, W, Cin, KH, KW, KH / 2, KW / 2, (int)ldx};
+  const int x16 = (flags & TATT_X_BF16) != 0, dy16 = (flags & TATT_DY_BF16) != 0;
+  TATT_CHECK_ARG(!(x16 || dy16) || (Cout > 16 && lddy % 4 == 0 && (((uintptr_t)dY) & 15) == 0),
+                 "tatt_conv_wgrad: bf16-stored operands need more than 16 output channels and a 16-byte granular dY");
   int perm = 1, perm_c = Cin;
   if (Cout <= 16 && Cout % 4 == 0 && lddy % 4 == 0 && (((uintptr_t)dY) & 15) == 0) {
     // tiny Cout (the 9x9 64->4 output conv): swap the roles of X and dY so that the wide tensor sits on the M side and
@@ -1792,12 +1858,14 @@ int tatt_conv_wgrad(const float* X, const float* dY, float* dW, int B, int H, in
     a.ldc = a.N;
     a.sCz = (long)a.M * a.N;
     perm = 2;
+    a.a16 = x16; a.b16 = dy16;
     if (g_wgrad192 && a.bf16 == 0 && a.M % WG_BM == 0 && fast_ok<OP_IM2COL_M, OP_ROWCONTIG>(a)) {
       hipLaunchKernelGGL(wgrad192_kernel, dim3(a.M / WG_BM, 1, splitk), dim3(WG_THR), 0, st, a);
       TATT_LAUNCH_CHECK("wgrad192_kernel");
     } else if (int rc = launch<OP_IM2COL_M, OP_ROWCONTIG>(a, 1, st)) return rc;
   } else {
     // the kernel treats splitk>1 as "write raw slabs"; with splitk==1 it applies bias/accumulate (none set): same result.
+    a.a16 = dy16; a.b16 = x16;
     if (int rc = launch<OP_ROWCONTIG, OP_IM2COL_N>(a, 1, st)) return rc;
   }
   long tot = (long)a.M * a.N;

@@ -155,7 +155,8 @@ __global__ void bn_stat_from_running(const float* __restrict__ rm, const float* 
 // act: 0 none, 1 relu, 2 mish.  y = act(bn(x)) (+ res).  ACT is a template parameter and the row tail is handled by clamping the
 // load row (stores predicated): with a run-time `act` and `if (r < R)` around every load the compiler emitted a basic block per
 // load with vmcnt(0) behind it -- the loads went out one at a time.
-template <int ACT>
+// OUT16: y is stored as bf16 (ldy in elements): the bf16 step keeps tensors that only bf16 matrix-core launches read in bf16.
+template <int ACT, bool OUT16 = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ stat,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ res, long ldr, float* __restrict__ y, long ldy, int R, int C) {
@@ -197,7 +198,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         else if (ACT == 2) t = mishf_(t);
         out[e] = t + ad[e];
       }
-      if (r < R) *reinterpret_cast<float4*>(y + (long)r * ldy + c) = make_float4(out[0], out[1], out[2], out[3]);
+      if constexpr (OUT16) {
+        if (r < R) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(y) + (long)r * ldy + c) = tatt_pack_bf16x4(out[0], out[1], out[2], out[3]);
+      } else {
+        if (r < R) *reinterpret_cast<float4*>(y + (long)r * ldy + c) = make_float4(out[0], out[1], out[2], out[3]);
+      }
     }
   }
 }
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ pa
 }
 
 // dx = gamma*invstd*(g - s1/R - xhat*s2/R) in training mode; eval mode (train=0): dx = gamma*invstd*g.  Branch-free like bn_apply_kernel.
-template <int ACT>
+template <int ACT, bool OUT16 = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy,
                                                     const float* __restrict__ stat, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, const float* __restrict__ sums, float* __restrict__ dx,
@@ -385,7 +390,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x,
         const float g = gi[e] * act_grad(xh * ga[e] + be[e], ACT);
         o[e] = ga[e] * inv[e] * (g - s1[e] - xh * s2[e]) + pi[e];
       }
-      if (r < R) *reinterpret_cast<float4*>(dx + (long)r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+      if constexpr (OUT16) {
+        if (r < R) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dx) + (long)r * lddx + c) = tatt_pack_bf16x4(o[0], o[1], o[2], o[3]);
+      } else {
+        if (r < R) *reinterpret_cast<float4*>(dx + (long)r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+      }
     }
   }
 }
@@ -755,6 +764,21 @@ int tatt_bn_apply(const float* x, long ldx, const float* stat, const float* gamm
   return TATT_OK;
 }
 
+// tatt_bn_apply with y stored as bf16 (round to nearest even; ldy in elements, y 8-byte aligned)
+int tatt_bn_apply_bf16(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr,
+                       uint16_t* y, long ldy, int R, int C, int act, hipStream_t st) {
+  TATT_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)y) & 7) == 0, "tatt_bn_apply_bf16: C/ld must be multiples of 4, y 8-byte aligned");
+  TATT_CHECK_ARG(act >= 0 && act <= 2 && R > 0, "tatt_bn_apply_bf16: act must be 0 (none), 1 (relu) or 2 (mish)");
+  float* yf = reinterpret_cast<float*>(y);
+#define BN_APPLY(A) hipLaunchKernelGGL((bn_apply_kernel<A, true>), dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, stat, gamma, beta, res, ldr, yf, ldy, R, C)
+  if (act == 0) BN_APPLY(0);
+  else if (act == 1) BN_APPLY(1);
+  else BN_APPLY(2);
+#undef BN_APPLY
+  TATT_LAUNCH_CHECK("bn_apply<bf16 out>");
+  return TATT_OK;
+}
+
 // Backward through y = act(bn(x)).  workspace: tatt_bn_workspace(C) floats.
 int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const float* stat, const float* gamma, const float* beta,
                 float* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int act, int train, int accumulate_params,
@@ -800,6 +824,20 @@ int tatt_bn_bwd_from_partial(const float* x, long ldx, const float* g, long ldg,
   hipLaunchKernelGGL(bn_bwd_apply<0>, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, g, ldg, stat, gamma, beta, sums, dx, lddx, R, C,
                      train, accumulate_dx);
   TATT_LAUNCH_CHECK("bn_bwd_apply");
+  return TATT_OK;
+}
+
+// tatt_bn_bwd_from_partial with dx stored as bf16 (no accumulation onto dx)
+int tatt_bn_bwd_from_partial_bf16(const float* x, long ldx, const float* g, long ldg, const float* stat, const float* gamma, const float* beta,
+                                  const float* partial, int nblk, uint16_t* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int train,
+                                  int accumulate_params, float* sums, hipStream_t st) {
+  TATT_CHECK_ARG(x && g && stat && gamma && beta && partial && dx && sums && nblk > 0 && C % 4 == 0 && (C <= 256 || C % 256 == 0) && lddx % 4 == 0 &&
+                     (((uintptr_t)dx) & 7) == 0, "tatt_bn_bwd_from_partial_bf16: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_final, dim3(cdiv(C, nblk > 128 ? 4 : 16)), dim3(256), 0, st, partial, nblk, C, sums, dgamma, dbeta, accumulate_params, nblk > 128 ? 4 : 16);
+  TATT_LAUNCH_CHECK("bn_bwd_final");
+  hipLaunchKernelGGL((bn_bwd_apply<0, true>), dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, g, ldg, stat, gamma, beta, sums, reinterpret_cast<float*>(dx),
+                     lddx, R, C, train, 0);
+  TATT_LAUNCH_CHECK("bn_bwd_apply<bf16 out>");
   return TATT_OK;
 }
 

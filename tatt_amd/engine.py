@@ -33,6 +33,7 @@ RPE_FINISH_EARLY = os.environ.get("TATT_RPE_FINISH_EARLY", "1") != "0"   # 0: jo
 STN_FC_SPLITK = int(os.environ.get("TATT_STN_FC_SPLITK", "8"))   # split-K factor of the STN head's fc products (1: none; A/B runs)
 STN_SMALL = os.environ.get("TATT_STN_SMALL", "1") != "0"   # 0: the STN head's small maps through the generic BatchNorm / pool launches (A/B runs)
 GRU_RES = os.environ.get("TATT_GRU_RES", "1") != "0"       # 0: "x + residual" of an SRB as an element-wise launch of its own (A/B runs)
+BF16_STORE = os.environ.get("TATT_BF16_STORE", "1") != "0"   # 0: the bf16 step keeps every tensor fp32 in memory (A/B runs; bit-identical results)
 WGRAD192_WGS = int(os.environ.get("TATT_WGRAD192_WGS", "255"))
 WGRAD_WGS = int(os.environ.get("TATT_WGRAD_WGS", "480"))   # workgroups of a convolution weight-gradient launch (split-K factor = this / tiles)
 NODROP = (0, 0, 1.0, None)
@@ -87,6 +88,13 @@ class Engine:
         # the output conv feeds the sigmoid directly -- their rounding error is amplified instead of averaged out.
         # self.px: what a call site pinned with fp32=True gets -- 0 (fp32 MFMA) unless the mode itself has fp32 accuracy (f32x3).
         self.pf, self.pl, self.px = 0, 0, 0
+        # bf16 STORAGE (bf16 mode, training): a tensor whose every reader is a bf16 matrix-core launch is written ONCE as bf16 by its
+        # producer and read as bf16 (flags TATT_X_BF16 / TATT_DY_BF16) -- per SRB mish(bn1(conv1)) (read by conv2 and conv2's weight
+        # gradient) and the gradients d conv2-out / d conv1-out (read by that convolution's dgrad and wgrad), block7's output + skip (read
+        # by the up-sampling convolution and its weight gradient), d block7-conv-out and the [R,256] gradient of the up-sampling
+        # convolution's output.  The readers rounded exactly these values to bf16 on their way into LDS before, so the step's numbers
+        # do not change by a bit (tests/test_gpu_bf16.py); what changes is 0.5 GB less HBM traffic per step at B = 64.
+        self.store16 = False
         self._rpe_chain_ok = None
         self.dec_fused = DEC_FUSED   # the TP interpreter's decoder as tatt_dec_fwd / tatt_dec_bwd (False: one launch per op; tests compare the two)
         self._rpe_sync = self._rpe_sync_b = None
@@ -222,6 +230,13 @@ class Engine:
     def new(self, *shape):
         return torch.empty(shape, device=self.dev, dtype=torch.float32)
 
+    def new16(self, *shape):
+        return torch.empty(shape, device=self.dev, dtype=torch.bfloat16)
+
+    @staticmethod
+    def _x16(t):
+        return 8 if t.dtype == torch.bfloat16 else 0          # TATT_X_BF16
+
     def zeros(self, *shape):
         return torch.zeros(shape, device=self.dev, dtype=torch.float32)
 
@@ -296,6 +311,8 @@ class Engine:
                         [p[1] for p in ch])
 
     def colsum(self, x, R, C, out, ld=None):
+        if x.dtype != torch.float32:
+            raise RuntimeError("colsum: fp32 input (a tensor the bf16 step stores as bf16 has no fp32 reader)")
         self._wgrad(lambda ws: self.L.colsum(x, ld or C, R, C, out, 1, ws), [x])
 
     def _skinny(self, x, W, b, out, B, H, Wd, Cin, Cout, k, wstr, acc, fp32=False):
@@ -357,7 +374,7 @@ class Engine:
         if Cout in (4, 8, 16) and not relu:
             return self._skinny(x, W, b, out, B, H, Wd, Cin, Cout, k, (Cin * T, T, 0, 1), acc, fp32)
         self.L.conv_fwd_splitk(x, self._packed(W, Cout, Cin, k)[0], b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout,
-                               T * Cin, 1, 0, Cin, acc, relu | (self.px if fp32 else self.pf), self._conv_splitk(B * H * Wd, Cout, T * Cin),
+                               T * Cin, 1, 0, Cin, acc, relu | (self.px if fp32 else self.pf) | self._x16(x), self._conv_splitk(B * H * Wd, Cout, T * Cin),
                                self.ws)
 
     def conv_dgrad(self, dy, W, dx, B, H, Wd, Cin, Cout, k, acc=0, fp32=False):
@@ -367,7 +384,7 @@ class Engine:
         if Cin in (4, 8, 16):
             return self._skinny(dy, W, None, dx, B, H, Wd, Cout, Cin, k, (T, Cin * T, T - 1, -1), acc, fp32)
         self.L.conv_fwd_splitk(dy, self._packed(W, Cout, Cin, k)[1], None, dx, B, H, Wd, Cout, Cin, k, k, Cout, Cin,
-                               T * Cout, 1, 0, Cout, acc, self.px if fp32 else self.pf, self._conv_splitk(B * H * Wd, Cin, T * Cout), self.ws)
+                               T * Cout, 1, 0, Cout, acc, (self.px if fp32 else self.pf) | self._x16(dy), self._conv_splitk(B * H * Wd, Cin, T * Cout), self.ws)
 
     def conv_wgrad(self, x, dy, dW, db, B, H, Wd, Cin, Cout, k, fp32=False, bias_grad=True):
         """bias_grad=False: the convolution feeds a training-mode BatchNorm, whose input gradient sums to zero over the rows for
@@ -388,7 +405,7 @@ class Engine:
         sk = max(1, min((B * H * Wd) // 256, sk))        # 3x3 64->64: 96 slabs; in the step 7.10 ms against 7.20 with 154 (standalone 57.7 / 61.0 us, and a shorter slab sum)
         while sk > 1 and Cout * T * Cin * sk > WS_FLOATS:
             sk //= 2
-        fl = 1 | (self.px if fp32 else self.pf)
+        fl = 1 | (self.px if fp32 else self.pf) | self._x16(x) | 2 * self._x16(dy)   # TATT_X_BF16 = 8, TATT_DY_BF16 = 16
         self._wgrad(lambda ws: self.L.conv_wgrad(x, dy, dW, B, H, Wd, Cin, Cout, k, k, Cin, Cout, sk, ws, fl), [dy], [x])
         if bias_grad:
             self.colsum(dy, B * H * Wd, Cout, db)
@@ -407,10 +424,11 @@ class Engine:
 
     # ---- BatchNorm fused into the producing launch (tatt_conv_fwd_bn / tatt_gemm_cat_bnbwd): the row reductions of both passes run
     # in the epilogue of the convolution / GEMM that writes the tensor, one (mean, M2) or (sum g, sum g xhat) pair per 128-row tile
-    def conv_bn(self, pre_bn, x, W, b, B, H, Wd, Cin, Cout, k, train, act, res=None, ng=1):
+    def conv_bn(self, pre_bn, x, W, b, B, H, Wd, Cin, Cout, k, train, act, res=None, ng=1, out16=False):
         """y = act(BatchNorm(conv(x))) (+ res).  Training mode: batch statistics from the convolution's epilogue.
         Returns (conv output, y, stat).  ng = 2: the B images are two passes of B/2 (the batched TSC step): ONE convolution launch,
-        BatchNorm statistics / running-statistic updates / apply per pass, in pass order; stat is then [2][2][Cout]."""
+        BatchNorm statistics / running-statistic updates / apply per pass, in pass order; stat is then [2][2][Cout].
+        out16: y is read by bf16 matrix-core launches only -- stored as bf16 when the step keeps such tensors in bf16 (self.store16)."""
         P, R, T = self.P, B * H * Wd, k * k
         c = self.new(R, Cout)
         if not train:
@@ -424,16 +442,17 @@ class Engine:
             raise RuntimeError("conv_bn: rows per pass must be a multiple of 128")
         nblk = Rg // 128
         part = self.new(ng * nblk * 2 * Cout)
-        self.L.conv_fwd_bn(x, self._packed(W, Cout, Cin, k)[0], b, c, B, H, Wd, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, self.pf, 1,
+        self.L.conv_fwd_bn(x, self._packed(W, Cout, Cin, k)[0], b, c, B, H, Wd, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, self.pf | self._x16(x), 1,
                            None, 0, None, None, None, 0, part)
         stat = self.new(ng, 2, Cout)
-        y = self.new(R, Cout)
+        y = self.new16(R, Cout) if (out16 and self.store16) else self.new(R, Cout)
+        apply = self.L.bn_apply_bf16 if y.dtype == torch.bfloat16 else self.L.bn_apply
         for g in range(ng):
             self.L.bn_stats_from_partial(part[g * nblk * 2 * Cout:], nblk, 128, Rg, Cout, 1e-5, 0.1, stat[g], P[pre_bn + "running_mean"],
                                          P[pre_bn + "running_var"])
             self._nbt.append(P[pre_bn + "num_batches_tracked"])
-            self.L.bn_apply(c[g * Rg:], Cout, stat[g], P[pre_bn + "weight"], P[pre_bn + "bias"], None if res is None else res[g * Rg:], Cout,
-                            y[g * Rg:], Cout, Rg, Cout, act)
+            apply(c[g * Rg:], Cout, stat[g], P[pre_bn + "weight"], P[pre_bn + "bias"], None if res is None else res[g * Rg:], Cout,
+                  y[g * Rg:], Cout, Rg, Cout, act)
         return c, y, (stat[0] if ng == 1 else stat)
 
     def conv_dgrad_bn(self, dy, W, B, H, Wd, Cin, Cout, k, pre_bn, bn_x, stat, act, train, G, ng=1):
@@ -444,17 +463,22 @@ class Engine:
         g = self.new(R, Cin)
         Rg, Bg = R // ng, B // ng
         nblk = -(-Rg // 128)
-        dx = self.new(R, Cin)
+        dx = self.new16(R, Cin) if self.store16 else self.new(R, Cin)   # read by the convolution's dgrad / wgrad launches only
         for q in range(ng):
             part = self.new(nblk * 2 * Cin)
             st = stat if ng == 1 else stat[q]
             self.L.conv_fwd_bn(dy[q * Rg:], self._packed(W, Cout, Cin, k)[1], None, g[q * Rg:], Bg, H, Wd, Cout, Cin, k, k, Cout, Cin, T * Cout, 1, 0,
-                               Cout, self.pf, 2, bn_x[q * Rg:], Cin, st, P[pre_bn + "weight"], P[pre_bn + "bias"], act, part)
+                               Cout, self.pf | self._x16(dy), 2, bn_x[q * Rg:], Cin, st, P[pre_bn + "weight"], P[pre_bn + "bias"], act, part)
             self.bn_bwd_part(pre_bn, bn_x[q * Rg:], g[q * Rg:], st, part, nblk, Rg, Cin, train, G, dx=dx[q * Rg:])
         return g, dx
 
-    def bn_bwd_part(self, pre, x, g, stat, part, nblk, R, C, train, G, dx=None):
-        dx = self.new(R, C) if dx is None else dx
+    def bn_bwd_part(self, pre, x, g, stat, part, nblk, R, C, train, G, dx=None, out16=False):
+        if dx is None:
+            dx = self.new16(R, C) if (out16 and self.store16) else self.new(R, C)
+        if dx.dtype == torch.bfloat16:
+            self.L.bn_bwd_from_partial_bf16(x, C, g, C, stat, self.P[pre + "weight"], self.P[pre + "bias"], part, nblk, dx, C, G[pre + "weight"],
+                                            G[pre + "bias"], R, C, 1 if train else 0, 1, self.new(2 * C))
+            return dx
         self.L.bn_bwd_from_partial(x, C, g, C, stat, self.P[pre + "weight"], self.P[pre + "bias"], part, nblk, dx, C, G[pre + "weight"],
                                    G[pre + "bias"], R, C, 1 if train else 0, 1, 0, self.new(2 * C))
         return dx
@@ -811,6 +835,7 @@ class Engine:
         # Linear / GRU-projection GEMMs and the sites bf16 mode pins to fp32: split products (fp32 accuracy) in both non-default modes
         # (bf16 mode: 6.77 -> 6.62 ms against fp32 MFMA on those launches, same error as before: 6.1e-3 max-abs at B=4)
         self.pl = self.px = ctx["pl"] = 0 if prec == "fp32" else 4
+        self.store16 = ctx["s16"] = bool(prec == "bf16" and training and BF16_STORE and getattr(m, "bf16_storage", True))
         ctx["meta"] = (B, training, seed, p)
         ctx["ng"], ctx["seeds"] = ng, seeds
         self.wpack = ctx["wpack"] = {} if wpack is None else wpack   # weights change every step: repacked per forward call
@@ -993,7 +1018,7 @@ class Engine:
         # The first SRB's convolutions (conv-BN-mish-conv-BN, model/tsrn.py:333-338) need block1's output only: they go here,
         # ahead of the decoder, where the main chain would otherwise sit waiting for the RPE chain's query_pos.
         def srb_convs(pre, blk):
-            ca, ma, st1 = self.conv_bn(pre + "bn1.", blk, P[pre + "conv1.weight"], P[pre + "conv1.bias"], Bt, H, W, 64, 64, 3, training, 2, ng=ng)
+            ca, ma, st1 = self.conv_bn(pre + "bn1.", blk, P[pre + "conv1.weight"], P[pre + "conv1.bias"], Bt, H, W, 64, 64, 3, training, 2, ng=ng, out16=True)
             cb, r2, st2 = self.conv_bn(pre + "bn2.", ma, P[pre + "conv2.weight"], P[pre + "conv2.bias"], Bt, H, W, 64, 64, 3, training, 0, ng=ng)
             return ca, ma, st1, cb, r2, st2
         first_convs = srb_convs("block2.", b1) if m.srb_nums > 0 else None
@@ -1049,7 +1074,7 @@ class Engine:
 
         # ---- block7 (conv+BN) + global residual, block8 (upsample + 9x9) + sigmoid ---------------------------------------
         k7 = f"block{m.srb_nums + 2}."
-        c7, u_in, st7 = self.conv_bn(k7 + "1.", blk, P[k7 + "0.weight"], P[k7 + "0.bias"], Bt, H, W, 64, 64, 3, training, 0, res=b1, ng=ng)
+        c7, u_in, st7 = self.conv_bn(k7 + "1.", blk, P[k7 + "0.weight"], P[k7 + "0.bias"], Bt, H, W, 64, 64, 3, training, 0, res=b1, ng=ng, out16=True)
         k8 = f"block{m.srb_nums + 3}."
         cu = self.new(Ra, 256)
         self.conv(u_in, P[k8 + "0.conv.weight"], P[k8 + "0.conv.bias"], cu, Bt, H, W, 64, 256, 3)
@@ -1116,6 +1141,7 @@ class Engine:
         ng, seeds = ctx.get("ng", 1), ctx.get("seeds", [seed])    # ng = 2: a two-pass batch (forward(x2=...)); B is the size of ONE pass
         self.pf, self.pl = ctx["pf"], ctx.get("pl", 0)
         self.px = self.pl
+        self.store16 = ctx.get("s16", False)
         self.wpack = ctx["wpack"]
         cfgs = [lambda site, s_=s_: self.dropcfg(site, s_, p) for s_ in seeds]
         cfg = cfgs[0]
@@ -1135,9 +1161,17 @@ class Engine:
         self.conv_wgrad(up, dpre, G[k8 + "1.weight"], G[k8 + "1.bias"], Bt, 2 * H, 2 * W, 64, 4, 9, fp32=True)
         dup = self.new(4 * Ra, 64)
         self.conv_dgrad(dpre, P[k8 + "1.weight"], dup, Bt, 2 * H, 2 * W, 64, 4, 9, fp32=True)
-        dcu = self.new(Ra, 256)
-        L.pixshuf_mish_bwd(cu, dup, dcu, Bt, H, W, 64)
-        self.conv_wgrad(u_in, dcu, G[k8 + "0.conv.weight"], G[k8 + "0.conv.bias"], Bt, H, W, 64, 256, 3)
+        if self.store16:
+            # read by the up-sampling convolution's dgrad / wgrad launches only: stored as bf16; the convolution's bias gradient (the
+            # column sum of the unrounded values) comes from per-block fp32 sums the same launch writes on the side
+            dcu, colpart = self.new16(Ra, 256), self.new(L.pixshuf_colpart_rows(Bt, H, W), 256)
+            L.pixshuf_mish_bwd_bf16(cu, dup, dcu, colpart, Bt, H, W, 64)
+            self.conv_wgrad(u_in, dcu, G[k8 + "0.conv.weight"], None, Bt, H, W, 64, 256, 3, bias_grad=False)
+            self.colsum(colpart, colpart.shape[0], 256, G[k8 + "0.conv.bias"])
+        else:
+            dcu = self.new(Ra, 256)
+            L.pixshuf_mish_bwd(cu, dup, dcu, Bt, H, W, 64)
+            self.conv_wgrad(u_in, dcu, G[k8 + "0.conv.weight"], G[k8 + "0.conv.bias"], Bt, H, W, 64, 256, 3)
         # grad of block1's output (accumulated below) = grad of u_in = bn(c7) + b1: the BatchNorm's reduction runs in the dgrad epilogue
         db1, dc7 = self.conv_dgrad_bn(dcu, P[k8 + "0.conv.weight"], Bt, H, W, 64, 256, 3, k7 + "1.", c7, st7, 0, training, G, ng=ng)
         self.conv_wgrad(blk_last, dc7, G[k7 + "0.weight"], G[k7 + "0.bias"], Bt, H, W, 64, 64, 3, bias_grad=not training)
@@ -1166,9 +1200,9 @@ class Engine:
             first_tp = False
             self._w_flush()
             if ng == 1:
-                dcb = self.bn_bwd_part(pre + "bn2.", cb, dr2, st2, parts, nblk, R0, 64, training, G)
+                dcb = self.bn_bwd_part(pre + "bn2.", cb, dr2, st2, parts, nblk, R0, 64, training, G, out16=True)
             else:
-                dcb = self.new(Ra, 64)
+                dcb = self.new16(Ra, 64) if self.store16 else self.new(Ra, 64)
                 for q_ in range(ng):
                     self.bn_bwd_part(pre + "bn2.", cb[q_ * R0:], dr2[q_ * R0:], st2[q_], parts[q_], nblk, R0, 64, training, G, dx=dcb[q_ * R0:])
             self.conv_wgrad(ma, dcb, G[pre + "conv2.weight"], G[pre + "conv2.bias"], Bt, H, W, 64, 64, 3, bias_grad=not training)

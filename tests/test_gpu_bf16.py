@@ -125,3 +125,121 @@ def test_model_forward_backward_within_bf16_tolerance():
     assert abs(loss.item() - loss64.item()) <= 1e-2 * abs(loss64.item())
     assert cos >= 0.999, cos
     assert d < d_ac and cos > cos_ac                           # and far inside what stock autocast(bfloat16) gives on this network
+
+
+# ---- bf16 STORAGE: tensors that only bf16 matrix-core launches read are written once as bf16 and read as bf16 (TATT_X_BF16 = 8,
+# TATT_DY_BF16 = 16).  Rounding at the producer instead of at every reader gives the same bits, so every test here is an equality.
+X16, DY16 = 8, 16
+
+
+def test_producers_store_the_rounding_of_the_fp32_result():
+    R, C = 2 * 16 * 64 + 8, 64                                      # a row tail
+    x, res = rnd(R, C).cuda(), rnd(R, C, seed=1).cuda()
+    stat = torch.stack([rnd(C, seed=2) * 0.1, 1 + rnd(C, seed=3).abs()]).cuda()
+    ga, be = (1 + 0.1 * rnd(C, seed=4)).cuda(), (0.1 * rnd(C, seed=5)).cuda()
+    for act, r_ in ((2, None), (0, res), (1, res)):
+        y, y16 = torch.empty(R, C, device="cuda"), torch.empty(R, C, device="cuda", dtype=torch.bfloat16)
+        L().bn_apply(x, C, stat, ga, be, r_, C, y, C, R, C, act)
+        L().bn_apply_bf16(x, C, stat, ga, be, r_, C, y16, C, R, C, act)
+        assert torch.equal(y16, y.bfloat16()), f"bn_apply_bf16 act {act}"
+    g = rnd(R, C, seed=6).cuda()
+    nblk = -(-R // 128)
+    part = rnd(nblk, 2, C, seed=7).cuda()
+    dG = [torch.zeros(C, device="cuda") for _ in range(4)]
+    dx, dx16 = torch.empty(R, C, device="cuda"), torch.empty(R, C, device="cuda", dtype=torch.bfloat16)
+    L().bn_bwd_from_partial(x, C, g, C, stat, ga, be, part, nblk, dx, C, dG[0], dG[1], R, C, 1, 1, 0, torch.empty(2 * C, device="cuda"))
+    L().bn_bwd_from_partial_bf16(x, C, g, C, stat, ga, be, part, nblk, dx16, C, dG[2], dG[3], R, C, 1, 1, torch.empty(2 * C, device="cuda"))
+    assert torch.equal(dx16, dx.bfloat16()) and torch.equal(dG[0], dG[2]) and torch.equal(dG[1], dG[3])
+    B, H, W = 2, 16, 64
+    cu, dup = rnd(B * H * W, 256, seed=8).cuda(), rnd(4 * B * H * W, 64, seed=9).cuda()
+    d, d16 = torch.empty(B * H * W, 256, device="cuda"), torch.empty(B * H * W, 256, device="cuda", dtype=torch.bfloat16)
+    L().pixshuf_mish_bwd(cu, dup, d, B, H, W, 64)
+    colpart = torch.empty(L().pixshuf_colpart_rows(B, H, W), 256, device="cuda")
+    L().pixshuf_mish_bwd_bf16(cu, dup, d16, colpart, B, H, W, 64)
+    assert torch.equal(d16, d.bfloat16())
+    close(colpart.sum(0), d.double().sum(0).cpu(), 2e-6, "column sums of the unrounded gradient")
+    d16.zero_()
+    L().pixshuf_mish_bwd_bf16(cu, dup, d16, None, B, H, W, 64)
+    assert torch.equal(d16, d.bfloat16())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 64, 64, 64), (2, 16, 64, 64, 256), (2, 16, 64, 256, 64), (3, 3, 32, 64, 64), (1, 6, 64, 32, 96)])
+def test_convolutions_read_bf16_stored_operands(B, H, W, Cin, Cout):
+    """forward / dgrad (plain and with both BatchNorm epilogues) and the weight gradient with X and / or dY stored as bf16 = the same
+    launch on the widened copies, bit for bit: LDS-halo kernel (W = 64, even H, Cin = 64), tap-generic loader (Cin = 256, odd H, W = 32)."""
+    k, T = 3, 9
+    R = B * H * W
+    x16 = rnd(R, Cin).cuda().bfloat16()
+    xf = x16.float()
+    w = (rnd(Cout, Cin, k, k, seed=1) / math.sqrt(Cin * T)).cuda()
+    wf, wd = torch.empty(w.numel(), device="cuda"), torch.empty(w.numel(), device="cuda")
+    L().conv_pack_w(w, wf, wd, Cout, Cin, k, k)
+    bias = rnd(Cout, seed=2).cuda()
+    a, b_ = torch.empty(R, Cout, device="cuda"), torch.empty(R, Cout, device="cuda")
+    L().conv_fwd(xf, wf, bias, a, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, 0, BF16)
+    L().conv_fwd(x16, wf, bias, b_, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, 0, BF16 | X16)
+    assert torch.equal(a, b_), "conv_fwd"
+    b_.copy_(a)
+    L().conv_fwd(xf, wf, None, a, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, 1, BF16)          # accumulate (dgrad onto a sum)
+    L().conv_fwd(x16, wf, None, b_, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, 1, BF16 | X16)
+    assert torch.equal(a, b_), "conv_fwd accumulate"
+    if R % 128 == 0:
+        nblk = R // 128
+        pa, pb = torch.empty(nblk, 2, Cout, device="cuda"), torch.empty(nblk, 2, Cout, device="cuda")
+        L().conv_fwd_bn(xf, wf, bias, a, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, BF16, 1, None, 0, None, None, None, 0, pa)
+        L().conv_fwd_bn(x16, wf, bias, b_, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, BF16 | X16, 1, None, 0, None, None, None, 0, pb)
+        assert torch.equal(a, b_) and torch.equal(pa, pb), "conv_fwd_bn epilogue 1"
+        bnx = rnd(R, Cout, seed=3).cuda()
+        stat = torch.stack([rnd(Cout, seed=4) * 0.1, 1 + rnd(Cout, seed=5).abs()]).cuda()
+        ga, be = (1 + 0.1 * rnd(Cout, seed=6)).cuda(), (0.1 * rnd(Cout, seed=7)).cuda()
+        for act in (0, 2):
+            L().conv_fwd_bn(xf, wf, None, a, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, BF16, 2, bnx, Cout, stat, ga, be, act, pa)
+            L().conv_fwd_bn(x16, wf, None, b_, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, BF16 | X16, 2, bnx, Cout, stat, ga, be, act, pb)
+            assert torch.equal(a, b_) and torch.equal(pa, pb), f"conv_fwd_bn epilogue 2 act {act}"
+    dy16 = (rnd(R, Cout, seed=8) * 0.1).cuda().bfloat16()
+    dyf = dy16.float()
+    sk = max(1, min(R // 256, 16))
+    ref = torch.zeros(Cout, Cin, k, k, device="cuda")
+    L().conv_wgrad(xf, dyf, ref, B, H, W, Cin, Cout, k, k, Cin, Cout, sk, ws(), 1 | BF16)
+    combos = [(x16, dy16, X16 | DY16)] + ([(xf, dy16, DY16)] if Cout <= 64 else [])
+    for xx, dd, fl in combos:
+        got = torch.zeros(Cout, Cin, k, k, device="cuda")
+        L().conv_wgrad(xx, dd, got, B, H, W, Cin, Cout, k, k, Cin, Cout, sk, ws(), 1 | BF16 | fl)
+        assert torch.equal(got, ref), f"conv_wgrad flags {fl}"
+    with pytest.raises(RuntimeError):                               # bf16 storage is a property of the bf16 launches
+        L().conv_fwd(x16, wf, bias, b_, B, H, W, Cin, Cout, k, k, Cin, Cout, T * Cin, 1, 0, Cin, 0, X16)
+
+
+@pytest.mark.parametrize("tsc", [False, True])
+def test_step_with_bf16_storage_equals_step_without_bit_for_bit(tsc):
+    """The bf16 pass (one pass, and the two-pass TSC batch) with the trunk's bf16-read tensors stored as bf16 against the same pass
+    with every tensor fp32 in memory: output, BatchNorm statistics and every gradient identical; the stored tensors ARE bf16."""
+    from oracle import procgen
+    from tatt_amd.model.tsrn import TSRN_TL_TRANS
+    B, K = 8, 37
+    res = []
+    for store in (True, False):
+        m = TSRN_TL_TRANS(text_embedding=K)
+        m.load_state_dict(procgen.fill_state(m.state_dict(), seed=1))
+        m = m.cuda().train()
+        m.matmul_precision, m.bf16_storage, m.dropout_p = "bf16", store, 0.1
+        eng = m.engine()
+        hr, lr, tp = [t.cuda() for t in procgen.make_inputs(B, K, seed=3)]
+        lr2 = torch.flip(lr, dims=[3]).contiguous() if tsc else None
+        sr, ctx = eng.forward(lr, tp, True, 5, x2=lr2)
+        assert ctx["srbs"][0][3].dtype == (torch.bfloat16 if store else torch.float32)      # mish(bn1(conv1)) of the first SRB
+        assert ctx["tail"][3].dtype == (torch.bfloat16 if store else torch.float32)         # block7's output + skip
+        G = {n: torch.zeros_like(p) for n, p in m.named_parameters()}
+        eng.backward(ctx, torch.randn(sr.shape, generator=torch.Generator().manual_seed(0)).cuda(), G)
+        torch.cuda.synchronize()
+        res.append((sr, G, {k_: v.clone() for k_, v in m.state_dict().items()}))
+    (sa, Ga, Sa), (sb, Gb, Sb) = res
+    assert torch.equal(sa, sb)
+    # one gradient is equal to summation order only: the bias gradient of the up-sampling convolution, the column sum of a gradient
+    # that is stored as bf16 -- summed in fp32 from the unrounded values by the launch that writes it, per 64 pixels
+    kb = "block8.0.conv.bias"
+    bad = [n for n in Ga if n != kb and not torch.equal(Ga[n], Gb[n])]
+    assert not bad, bad[:5]
+    r = rel_l2(Ga[kb].cpu().numpy(), Gb[kb].cpu().numpy())
+    assert r < 5e-6, r
+    assert all(torch.equal(Sa[k_], Sb[k_]) for k_ in Sa)

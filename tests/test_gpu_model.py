@@ -433,3 +433,33 @@ def test_mask_false_three_channel_network_vs_oracle():
         if err > 2e-4 * ref.norm().item() + 1e-7 * tot:
             bad.append((n, err / max(ref.norm().item(), 1e-30)))
     assert not bad, f"mask=False eval-mode gradient mismatches vs fp64 oracle: {bad[:10]}"
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f32x3", "bf16"])
+def test_pass_is_reproducible_bit_for_bit(prec):
+    """The same B = 64 forward + backward pass four times: every gradient bit-identical.  The pass forks five streams (RPE chain, text
+    branch, two weight-gradient streams); nothing in it sums in a run-dependent order.  Before the library was built without
+    packed-fp32 VALU code (csrc/Makefile, NOPK) the f32x3 and bf16 passes failed this in about half of the runs: dec_bwd_kernel and
+    tps_sample_bwd_k returned wrong lanes beside the split-product weight-gradient kernels (tools/probe_determinism.py)."""
+    B, K = 64, 37
+    m = build(K).train()
+    m.dropout_p = 0.0
+    m.matmul_precision = prec
+    hr, lr, tp = [t.cuda() for t in procgen.make_inputs(B, K, seed=0)]
+    eng = m.engine()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    ref = None
+    for r in range(4):
+        m.load_state_dict(sd0)
+        sr, ctx = eng.forward(lr, tp, True, 0, p_drop=0.0)
+        dsr = torch.empty_like(sr)
+        eng.L.image_loss_bwd(sr, hr, None, 100.0 / B, dsr, B, 4, 32, 128, 1.0, 1e-4)
+        G = {n: torch.zeros_like(q) for n, q in m.named_parameters()}
+        eng.backward(ctx, dsr, G)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = (sr.clone(), G)
+            continue
+        assert torch.equal(sr, ref[0]), f"pass {r}: output differs from pass 0"
+        bad = [n for n in G if not torch.equal(G[n], ref[1][n])]
+        assert not bad, f"pass {r}: {len(bad)} gradients differ from pass 0, e.g. {bad[:4]}"
