@@ -121,7 +121,7 @@ def in_step_launch_us():
         return None
     calls = us = 0.0
     for line in open(files[-1]):
-        m = re.match(r"gemm_kernel<2, 6, true, false, true, \d>\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)", line)
+        m = re.match(r"gemm_kernel<2, 6, true, false, true, \d(?:, false, false)?>\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)", line)
         if m:
             calls += float(m.group(1))
             us += float(m.group(2)) * 1e3
