@@ -221,7 +221,15 @@ def main():
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    if world > 1:
+    # TATT_BENCH_FORCE_PG=1: the data-parallel code path (segmented graphs, bucketed all-reduce) through a ONE-rank RCCL group: what the
+    # path itself costs on one GPU, before any link is involved (experiment; the line then carries `data_parallel`)
+    use_pg = world > 1 or os.environ.get("TATT_BENCH_FORCE_PG", "0") == "1"
+    if use_pg:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from tatt_amd.data import synthetic_batch
@@ -249,9 +257,9 @@ def main():
 
     for _ in range(a.warmup):
         trainer.step(lr, hr, tp)
-    trainer.time_comm = world > 1                    # events around the un-overlapped part of the gradient all-reduce
+    trainer.time_comm = use_pg                       # events around the un-overlapped part of the gradient all-reduce
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -259,13 +267,13 @@ def main():
     for i in range(a.steps):
         per = trainer.step(lr, hr, tp)
         marks[i + 1].record()                        # per-step device times (median / p90 below); the metric uses the wall clock
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     dt_local = dt = time.perf_counter() - t0
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     dp = {}
-    if world > 1:
+    if use_pg:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
@@ -280,7 +288,8 @@ def main():
               "backend": dist.get_backend(), "rank_ms_per_step_min": round(min(dts) / a.steps * 1e3, 3),
               "rank_ms_per_step_max": round(max(dts) / a.steps * 1e3, 3),
               "allreduce_ms_exposed": round(trainer.exposed_comm_ms(), 4), "grad_bytes_per_step": int(trainer.n) * 4,
-              "buckets": [int(b - a_) * 4 for a_, b in trainer.bucket_range]}
+              "buckets": [int(b - a_) * 4 for a_, b in trainer.bucket_range],
+              "collective_bytes": [int(v.numel()) * 4 for st in ("srbs", "infogen") for v in trainer._bucket_views(st)]}
     trainer.check_chains()                           # the single-launch recurrences (RPE, LSTM) report timed-out waits in a flag word: fail loudly
     loss = float(per.mean().item()) * 100
     if not (loss == loss and loss < 1e6):
@@ -321,7 +330,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and not a.tsc and not a.full:
             out["cpu_baseline"] = cpu_baseline(state_cpu, a.batch, a.K)
         print(json.dumps(out), file=real_stdout, flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

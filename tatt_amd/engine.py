@@ -1101,7 +1101,8 @@ class Engine:
     def _backward(self, ctx, dsr, G, on_stage=None):
         """Accumulates parameter gradients of one forward call into G (dict name -> fp32 tensor).
         on_stage(name) is called when a gradient bucket is complete ("tail", "srbs", then "head" and "infogen" together at the end):
-        the data-parallel trainer starts that bucket's all-reduce there, overlapping the rest of the pass."""
+        the data-parallel trainer starts all-reduces there, overlapping the rest of the pass.  A callback with a `stages` attribute is
+        called for those names only (the weight-gradient streams are joined only where the caller acts on the announcement)."""
         user_stage = on_stage
         self._w_keep, self._w_pending, self._w_defer = [], set(), []   # nothing may survive from a pass that raised half way
 
@@ -1121,8 +1122,10 @@ class Engine:
                                     arr([G[u[0] + "conv1.bias"] for u in un]), (ctypes.c_int * n_)(*[u[4] for u in un]))
             self._gru_unfold = []
 
+        wanted = getattr(user_stage, "stages", ("tail", "srbs", "head", "infogen"))   # announcements the caller acts on
+
         def on_stage(name):                                   # a bucket is complete only once its weight gradients have landed
-            if user_stage is not None:
+            if user_stage is not None and name in wanted:
                 self._w_join()
                 if name == "srbs":
                     finish_unfold()

@@ -2,14 +2,14 @@
 restricted to BASELINE config 2: one SR forward/backward, ImageLoss.mean()*100, clip_grad_norm_ 0.25, Adam).
 
 Parameters and gradients live in two flat fp32 buffers laid out in the order the backward pass produces the
-gradients (tail -> SRBs -> TP interpreter -> block1/STN), so that data-parallel training all-reduces four
-contiguous buckets over RCCL while the rest of the backward pass is still running, and the fused
-clip+Adam kernel touches every parameter once.  Every nn.Parameter of the module stays a view of the flat
+gradients (tail -> SRBs -> TP interpreter -> block1/STN), so that data-parallel training all-reduces contiguous
+ranges over RCCL (two collectives per step: tail + SRBs while the rest of the backward pass is still running, then
+TP interpreter + block1/STN), and the fused clip+Adam kernel touches every parameter once.  Every nn.Parameter of the module stays a view of the flat
 buffer (state_dict / checkpoints are unaffected).
 
-Data parallel + hipGraph: the step is captured as THREE graphs cut at the bucket boundaries of the backward pass
-(forward + tail | SRBs | TP interpreter + block1/STN) plus one for clip+Adam; between two replays the finished
-bucket's all-reduce is issued on RCCL's own stream, so it is in flight while the next segment runs -- the same
+Data parallel + hipGraph: the step is captured as TWO graphs cut where the SRBs' gradients are complete
+(forward + tail + SRBs | TP interpreter + block1/STN) plus one for clip+Adam; between two replays the finished
+buckets' all-reduce is issued on RCCL's own stream, so it is in flight while the next segment runs -- the same
 overlap the eager path gets from Engine.backward(on_stage=...), and bit-identical to it.  How much can overlap is
 bounded by the network: the recurrent positional encoding's weights (19.6 MB of the 30.4 MB) and the STN head
 (7.4 MB) are the LAST gradients the backward pass produces, so only the tail and SRB buckets (3.3 MB) travel
@@ -23,6 +23,11 @@ import torch.distributed as dist
 from .lib import lib
 
 BUCKETS = ["tail", "srbs", "infogen", "head"]
+# Collectives of a data-parallel step: the backward pass announces a finished bucket (Engine.backward(on_stage=...)); at these two
+# announcements ONE all-reduce covers the adjacent buckets named (the flat layout keeps them contiguous).  Few, large collectives: the
+# tail bucket is 0.8 MB -- an all-reduce and a graph cut of its own cost more than its early start returned (one rank, B=64: the
+# four-segment step took 6.84 ms) -- and the two buckets that the pass finishes last go out as one 27 MB call.
+REDUCE_AT = {"srbs": ("tail", "srbs"), "infogen": ("infogen", "head")}
 
 
 def _bucket_of(name: str, srb_nums: int) -> int:
@@ -216,10 +221,11 @@ class SRTrainer:
 
         def on_stage(name):
             if overlap:
-                a, b = self.bucket_range[BUCKETS.index(name)]
-                works.append(allreduce_mean(self.flat_g[a:b], async_op=True))
+                if name in REDUCE_AT:
+                    works.extend(allreduce_mean(t, async_op=True) for t in self._bucket_views(name))
             elif cut is not None:
                 cut(name)
+        on_stage.stages = frozenset(REDUCE_AT)
 
         self.eng.backward(ctx, dsr, self.G, on_stage=on_stage if (overlap or cut is not None) else None)
         return per, works
@@ -260,8 +266,10 @@ class SRTrainer:
         """Buffers a forward pass updates in place (BatchNorm running statistics and counters)."""
         return [b for n, b in self.model.named_buffers() if "running_" in n or n.endswith("num_batches_tracked")]
 
-    def _bucket_views(self, name):
-        a, b = self.bucket_range[BUCKETS.index(name)]
+    def _bucket_views(self, stage):
+        """The slice of the flat gradient buffer that the collective issued at announcement `stage` reduces (REDUCE_AT)."""
+        first, last = REDUCE_AT[stage]
+        a, b = self.bucket_range[BUCKETS.index(first)][0], self.bucket_range[BUCKETS.index(last)][1]
         return [self.flat_g[a:b]]
 
     def _wait_all(self, works):
@@ -323,14 +331,14 @@ class SRTrainer:
             cur[0] = None
 
         def cut(name):                                    # Engine.backward has joined its weight-gradient streams here
-            if name in ("tail", "srbs"):
-                end([name])
+            if name == "srbs":
+                end(["srbs"])
                 begin()
         try:
             begin()
             self.per, _ = self._fwd_bwd(*self.static[:3], overlap=False, on_stage=cut if self.dp else None, **args)
             if self.dp:
-                end(["infogen", "head", "extra"])
+                end(["infogen", "extra"])
                 begin()
             self._update()
             end([])

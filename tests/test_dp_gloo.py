@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tatt_amd.trainer import BUCKETS, allreduce_mean, assert_replicas_identical, plan_flat_layout
+from tatt_amd.trainer import BUCKETS, REDUCE_AT, allreduce_mean, assert_replicas_identical, plan_flat_layout
 
 
 def _shapes():
@@ -43,8 +43,8 @@ def _worker(rank, world, port, q):
     g = torch.Generator().manual_seed(100 + rank)
     flat = torch.randn(total, generator=g)
     mine = flat.clone()
-    for a, b in ranges:                                   # same calls, same order as SRTrainer.on_stage
-        allreduce_mean(flat[a:b], async_op=True)
+    for first, last in REDUCE_AT.values():                # same calls, same order as SRTrainer.on_stage: two collectives per step
+        allreduce_mean(flat[ranges[BUCKETS.index(first)][0]:ranges[BUCKETS.index(last)][1]], async_op=True)
     other = torch.randn(total, generator=torch.Generator().manual_seed(100 + (1 - rank)))
     ok = torch.allclose(flat, (mine + other) / 2, atol=1e-6)
     # the replica self-check bench.py runs after its timed steps: passes on the (now identical) reduced buffer, raises on

@@ -58,8 +58,8 @@ def test_dp_path_over_rccl_matches_single_process_step(one_rank_group, graph):
 
 
 def test_graph_dp_is_segmented_at_bucket_boundaries_and_equals_eager_dp(one_rank_group):
-    """Data parallel + hipGraph: the step is captured as three segments cut where a gradient bucket is complete (the bucket's
-    all-reduce is issued between two replays and runs while the next segment executes) plus one clip+Adam graph; the result is
+    """Data parallel + hipGraph: the step is captured as two segments cut where the SRBs' gradients are complete (the all-reduce of
+    tail + SRBs is issued between the two replays and runs while the second segment executes) plus one clip+Adam graph; the result is
     bit-identical to the eager data-parallel step, which issues the same all-reduces from inside the backward pass."""
     from tatt_amd.trainer import SRTrainer
     state = make_state(K, seed=12)
@@ -71,7 +71,9 @@ def test_graph_dp_is_segmented_at_bucket_boundaries_and_equals_eager_dp(one_rank
         eager.step(lr, hr, tp)
         graph.step(lr, hr, tp)
     torch.cuda.synchronize()
-    assert [b for _, b in graph.graph] == [["tail"], ["srbs"], ["infogen", "head", "extra"]] and graph.graph_update is not None
+    assert [b for _, b in graph.graph] == [["srbs"], ["infogen", "extra"]] and graph.graph_update is not None
+    a, b = graph._bucket_views("srbs")[0], graph._bucket_views("infogen")[0]         # the two collectives tile the gradient buffer
+    assert a.data_ptr() == graph.flat_g.data_ptr() and b.data_ptr() == a.data_ptr() + 4 * a.numel() and a.numel() + b.numel() == graph.n
     assert torch.equal(eager.flat_g, graph.flat_g) and torch.equal(eager.flat_p, graph.flat_p)
     assert graph.exposed_comm_ms() >= 0.0 and graph.verify_replicas() == 1
 
