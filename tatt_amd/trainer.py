@@ -67,6 +67,22 @@ def allreduce_mean(t, async_op=False):
     return None
 
 
+def broadcast_buffers(bufs, src=0):
+    """Rank `src`'s module buffers on every rank: one collective per dtype over a packed copy (a CRNN + the SR net have a hundred
+    BatchNorm buffers of a few hundred bytes each; one broadcast per buffer is a hundred launches -- and, on a backend that stages
+    device tensors through the host, a hundred synchronisations)."""
+    groups = {}
+    for b in bufs:
+        groups.setdefault(b.dtype, []).append(b)
+    for same in groups.values():
+        flat = torch.cat([b.detach().reshape(-1) for b in same])
+        dist.broadcast(flat, src)
+        off = 0
+        for b in same:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+
+
 def replica_fingerprint(t):
     """(sum, sum of squares, two bit-pattern checksums) of a flat fp32 buffer as four float64 values: equal on every rank iff the
     replicas hold bit-identical parameters (up to a 2^-53-ish chance for the sums).  The checksums are position-weighted sums of
@@ -142,8 +158,7 @@ class SRTrainer:
             p.grad = self.G[n]
         if self.dp:                                           # identical replicas: rank 0's initial weights + buffers
             dist.broadcast(self.flat_p, 0)
-            for b in model.buffers():
-                dist.broadcast(b, 0)
+            broadcast_buffers(list(model.buffers()))
         self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int32)
         self.eng.seed_dev = self.seed_dev
         self.use_graph = use_graph
@@ -439,8 +454,7 @@ class TATTTrainer(SRTrainer):
             p.grad = self.G_s[k]
         if self.dp:
             dist.broadcast(self.s_p, 0)
-            for b in student.buffers():
-                dist.broadcast(b, 0)
+            broadcast_buffers(list(student.buffers()))
         self.loss_tp = None                                    # device scalar: SemanticLoss of the last step (L_TP = 100 x)
 
     def stateful_buffers(self):

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tatt_amd.trainer import BUCKETS, REDUCE_AT, allreduce_mean, assert_replicas_identical, plan_flat_layout
+from tatt_amd.trainer import BUCKETS, REDUCE_AT, allreduce_mean, assert_replicas_identical, broadcast_buffers, plan_flat_layout
 
 
 def _shapes():
@@ -57,6 +57,13 @@ def _worker(rank, world, port, q):
         ok = False
     except RuntimeError as e:
         ok = ok and "diverged" in str(e)
+    # module buffers: packed per dtype into one broadcast each, rank 0's values land in every rank's own tensors (shapes kept)
+    bufs = [torch.full((3, 5), float(rank + 1)), torch.tensor(7 + rank), torch.full((4,), rank + 2, dtype=torch.int64), torch.full((2, 2), 0.5 + rank)]
+    ptrs = [b.data_ptr() for b in bufs]
+    broadcast_buffers(bufs)
+    ok = ok and all(b.data_ptr() == p for b, p in zip(bufs, ptrs))
+    ok = ok and torch.equal(bufs[0], torch.full((3, 5), 1.0)) and int(bufs[1]) == 7 and torch.equal(bufs[2], torch.full((4,), 2, dtype=torch.int64))
+    ok = ok and torch.equal(bufs[3], torch.full((2, 2), 0.5))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
