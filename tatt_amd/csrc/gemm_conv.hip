@@ -221,6 +221,22 @@ constexpr int X3_BUF = 3 * (X3_A_PLANE + X3_B_PLANE);                 // bytes o
 constexpr int HALO_Q = 4 * 66;            // halo pixels of a 2 x 64 pixel tile
 constexpr int HALO_PLANE = HALO_Q * 64;   // bytes of one bf16 plane (32 channels)
 
+// Workgroups are dealt to the eight XCDs round-robin in dispatch order (x fastest), each XCD with an L2 of its own.  For a split-K
+// launch whose `per` tiles of one k-slab read the same operand slabs: dispatch index -> (tile s, slab z) such that the tiles of a
+// slab sit on ONE XCD, consecutive in its sequence (eight slabs at a time, one per XCD; the last nz % 8 slabs are dealt tile-major).
+__device__ __forceinline__ void xcd_slab_order(int lin, int per, int nz, int& s, int& z) {
+  const int full = nz & ~7;
+  if (lin < full * per) {
+    const int G = lin / (8 * per), r = lin - G * 8 * per;
+    z = G * 8 + (r & 7);
+    s = r >> 3;
+  } else {
+    const int r = lin - full * per, t = nz - full;
+    s = r / t;
+    z = full + r - s * t;
+  }
+}
+
 template <int AOP, int BOP, bool FAST, bool BF16, bool TAP9, int EPI, bool X3, bool HALO = false, bool A16 = false, bool B16 = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
   static_assert(!(A16 || B16) || (FAST && BF16), "bf16-stored operands feed the bf16 matrix-core launches (FAST loaders) only");
@@ -240,10 +256,29 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive M tiles -
   // which share their im2col halo rows - would land on 8 different L2s and every halo row would be fetched twice from
   // the fabric (measured: FETCH_SIZE = 2x the input).  Give each XCD a contiguous range of M tiles instead.
-  int bx = blockIdx.x;
-  if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
-  const int m0 = bx * BM, n0 = blockIdx.y * BN;
-  const int zb = blockIdx.z / a.splitk, zs = blockIdx.z % a.splitk;
+  // Tiles that read the same operand rows should also run at the same TIME on that XCD (round 3, whole-step FETCH_SIZE table,
+  // profiles/r03_step_traffic.md): the N tiles of one M tile used to be a whole grid row apart in dispatch order, so the GruBlock
+  // projections (N = 192: three N tiles) fetched their A rows up to three times; they are now consecutive in their XCD's sequence.
+  // Split-K launches with a handful of tiles per k-slab (the 9x9 and the up-sampling convolution's weight gradients: 3 and 18
+  // tiles that all read the same two pixel slabs) keep each slab's tiles on one XCD (xcd_slab_order).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if ((gridDim.x & 7) == 0) {
+    if (gridDim.y == 1) {
+      bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+    } else {
+      const int lin = bx + gridDim.x * by;  // dispatch order inside the z slice; lin & 7 = XCD
+      const int q = lin >> 3;
+      by = q % gridDim.y;
+      bx = (lin & 7) * (gridDim.x >> 3) + q / gridDim.y;
+    }
+  } else if (a.splitk > 1 && (int)gridDim.z == a.splitk && gridDim.x * gridDim.y <= 32) {
+    int s;
+    xcd_slab_order(bx + gridDim.x * (by + gridDim.y * bz), gridDim.x * gridDim.y, gridDim.z, s, bz);
+    by = s / gridDim.x;
+    bx = s - by * gridDim.x;
+  }
+  const int m0 = bx * BM, n0 = by * BN;
+  const int zb = bz / a.splitk, zs = bz % a.splitk;
   const float* __restrict__ Ap = a.A + zb * a.sAb;
   const float* __restrict__ Bp = a.B + zb * a.sBb;
   const int kbeg = zs * a.kchunk;
@@ -1395,8 +1430,11 @@ __global__ __launch_bounds__(WG_THR, 6) void wgrad192_kernel(GemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave % 3, wn = (wave / 3) & 1, kh = wave / 6;
-  const int m0 = blockIdx.x * WG_BM;
-  const int zs = blockIdx.z;
+  // the three M tiles of a k-slab read the same X and dY pixels: one XCD, side by side (reads per launch 94.9 -> 36.7 MiB against
+  // 32 algorithmic, profiles/r03_step_traffic.md)
+  int mt, zs;
+  xcd_slab_order(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x, gridDim.z, mt, zs);
+  const int m0 = mt * WG_BM;
   const int kbeg = zs * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
   const int ntiles = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(a.A), rsrcB = make_rsrc(a.B);

@@ -7,6 +7,7 @@
 // slabs to write and re-read) writes one partial slab, a second kernel sums the slabs in a fixed order (deterministic;
 // no atomics).  The bias gradient rides along on the already loaded dY fragments.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -167,7 +168,13 @@ struct TnGroup {
   float* db[TN_GROUP];
   long lddy[TN_GROUP], ldx[TN_GROUP], lddw[TN_GROUP], slab_off[TN_GROUP];
   int M[TN_GROUP], N[TN_GROUP], R[TN_GROUP], rpb[TN_GROUP], nblk[TN_GROUP];
-  int first[TN_GROUP + 1];  // problem p owns blocks [first[p], first[p + 1]) of the one-dimensional grid
+  int first[TN_GROUP + 1];  // problem p owns work items [first[p], first[p + 1])
+  // dispatch index -> (problem << 8 | row block): the problems of a group read the same tensors (a GruBlock's six share dgi, the
+  // block's inputs and h_prev between them), and workgroups are dealt to the eight XCDs round-robin, each XCD with an L2 of its
+  // own.  The host sorts the work items by the position of their row range and gives every XCD a contiguous run of them, so the
+  // items that read the same rows run on ONE XCD at the same time and every row crosses the fabric once instead of once per
+  // problem (whole-step FETCH_SIZE table, profiles/r03_step_traffic.md).
+  unsigned short wg[TN_MAXBLK];
 };
 
 __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_group_kernel(TnGroup g, float* __restrict__ slabs) {
@@ -175,10 +182,8 @@ __global__ __launch_bounds__(TN_WAVES * 64) void tn_small_group_kernel(TnGroup g
   // The grid is exactly the blocks that have work, problem after problem: at most one per CU, and the hardware's round-robin
   // of consecutive blocks over the eight XCDs then gives every XCD at most 32 of them.  (A [nb_max, nprob] grid whose surplus
   // blocks exit at once put up to 39 working blocks on one XCD: two rounds, 89 us instead of 56.)
-  int p = 0;
-#pragma unroll
-  for (int q = 1; q < TN_GROUP; ++q) p += (int)blockIdx.x >= g.first[q] ? 1 : 0;   // first[] is non-decreasing, padded with the total
-  const int blk = (int)blockIdx.x - g.first[p];
+  const int item = g.wg[blockIdx.x];
+  const int p = item >> 8, blk = item & 255;
   // block-uniform dispatch on the problem's tile shape (a per-MFMA "skip this tile" branch inside one shape split the loop into
   // a basic block per MFMA: nothing overlapped)
   const int mt = (g.M[p] + 31) >> 5, nt = (g.N[p] + 31) >> 5;
@@ -302,6 +307,29 @@ int tatt_tn_small_group(int nprob, const float* const* dY, const long* lddy, con
     if (per > per_max) per_max = per;
   }
   for (int p = nprob; p < TN_GROUP; ++p) g.first[p + 1] = g.first[nprob];
+  {
+    // work items sorted by where their row range lies (as a fraction of the problem's rows), dealt to the XCDs in contiguous runs:
+    // dispatch index i runs on XCD i % 8, so XCD x takes the sorted items [start_x, start_x + count_x) at indices x, x + 8, ...
+    const int total = g.first[nprob];
+    TATT_CHECK_ARG(total <= TN_MAXBLK, "tatt_tn_small_group: %d work items", total);
+    struct Item { double mid; unsigned short code; };
+    Item items[TN_MAXBLK];
+    int n = 0;
+    for (int p = 0; p < nprob; ++p)
+      for (int b = 0; b < g.nblk[p]; ++b) {
+        const double lo = (double)b * g.rpb[p], hi = lo + g.rpb[p] < g.R[p] ? lo + g.rpb[p] : (double)g.R[p];
+        items[n].mid = 0.5 * (lo + hi) / g.R[p];
+        items[n].code = (unsigned short)(p << 8 | b);
+        ++n;
+      }
+    std::stable_sort(items, items + n, [](const Item& a, const Item& b) { return a.mid < b.mid; });
+    int start = 0;
+    for (int x = 0; x < 8; ++x) {
+      const int count = total > x ? (total - x + 7) / 8 : 0;
+      for (int i = 0; i < count; ++i) g.wg[x + 8 * i] = items[start + i].code;
+      start += count;
+    }
+  }
   hipLaunchKernelGGL(tn_small_group_kernel, dim3(g.first[nprob]), dim3(TN_WAVES * 64), 0, st, g, workspace);
   TATT_LAUNCH_CHECK("tn_small_group_kernel");
   hipLaunchKernelGGL(tn_small_group_reduce, dim3(cdiv(per_max, 16), nprob), dim3(256), 0, st, g, workspace);
