@@ -272,6 +272,7 @@ int tatt_relu_drop_bwd(const float* h, const float* dh, float* out, long n, uint
 int tatt_tps_sample_fwd(const float* x, const float* ctrl, const float* T, float* y, float* src_out, int B, int C, int H, int W, hipStream_t stream);
 int tatt_tps_sample_bwd(const float* x, const float* ctrl, const float* T, const float* dy, float* dctrl, int B, int C, int H, int W, int accumulate, hipStream_t stream);
 int tatt_rotate_fwd(const float* x, const float* arc, float* y, int B, int C, int H, int W, hipStream_t stream);
+/* dx += rotate_fwd^T dy (the caller zeroes dx or holds a gradient to add to); a gather in a fixed summation order (no atomics), C <= 8 */
 int tatt_rotate_bwd(const float* arc, const float* dy, float* dx, int B, int C, int H, int W, hipStream_t stream);
 
 /* ---- TRI_SSIM, the TSC loss term (utils/ssim_psnr.py:99-128, :229-254; called at interfaces/super_resolution_eng.py:261),

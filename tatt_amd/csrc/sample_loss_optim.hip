@@ -103,26 +103,44 @@ __global__ void rotate_fwd_k(const float* __restrict__ x, const float* __restric
                                                   v10 * (1.f - bl.fx) * bl.fy + v11 * bl.fx * bl.fy;
   }
 }
-// dx (must be zeroed by the caller) += scatter of dy through the same sampling pattern
+// dx += the transpose of rotate_fwd applied to dy, as a GATHER: one thread per INPUT pixel q sums, in a fixed order, the
+// contributions of the output pixels whose four bilinear taps include q.  (The scatter form -- one thread per output pixel, four
+// float atomics -- was the library's one summation whose order changed from run to run.)  In pixel units centred on the image the
+// sampling position of output pixel (px, py) is a plain rotation of its centre: (ix', iy') = R(arc) (px + 1/2 - W/2, py + 1/2 - H/2),
+// so the output pixels that can touch q have their centre within sqrt(2) of R(-arc) q': a 5 x 5 window of candidates around it, each
+// re-evaluated with the forward kernel's own arithmetic (same x0 / y0 / fractions, bit for bit) and tested for a tap on q.
 __global__ void rotate_bwd_k(const float* __restrict__ arc, const float* __restrict__ dy, float* __restrict__ dx, int B, int C, int H,
                              int W) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * H * W) return;
-  int px = i % W, py = (i / W) % H, b = i / (H * W);
-  float r = (float)H / (float)W, c = cosf(arc[b]), s = sinf(arc[b]);
-  float bx = (2.f * px + 1.f) / W - 1.f, by = (2.f * py + 1.f) / H - 1.f;
-  float gx = c * bx + s * r * by, gy = (-s / r) * bx + c * by;
-  Bilin bl = bilin_setup(gx, gy, H, W);
-  float w00 = (1.f - bl.fx) * (1.f - bl.fy), w01 = bl.fx * (1.f - bl.fy), w10 = (1.f - bl.fx) * bl.fy, w11 = bl.fx * bl.fy;
-  for (int ch = 0; ch < C; ++ch) {
-    float g = dy[((long)b * C + ch) * H * W + py * W + px];
-    float* img = dx + ((long)b * C + ch) * H * W;
-    int x0 = bl.x0, y0 = bl.y0;
-    if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) atomicAdd(img + y0 * W + x0, g * w00);
-    if (x0 + 1 >= 0 && x0 + 1 < W && y0 >= 0 && y0 < H) atomicAdd(img + y0 * W + x0 + 1, g * w01);
-    if (x0 >= 0 && x0 < W && y0 + 1 >= 0 && y0 + 1 < H) atomicAdd(img + (y0 + 1) * W + x0, g * w10);
-    if (x0 + 1 >= 0 && x0 + 1 < W && y0 + 1 >= 0 && y0 + 1 < H) atomicAdd(img + (y0 + 1) * W + x0 + 1, g * w11);
+  const int qx = i % W, qy = (i / W) % H, b = i / (H * W);
+  const float r = (float)H / (float)W, c = cosf(arc[b]), s = sinf(arc[b]);
+  const float qa = qx + 0.5f - 0.5f * W, qb = qy + 0.5f - 0.5f * H;
+  const float u0 = c * qa - s * qb + 0.5f * W - 0.5f, v0 = s * qa + c * qb + 0.5f * H - 0.5f;   // output pixel whose sample point is q
+  const int cx = (int)floorf(u0 + 0.5f), cy = (int)floorf(v0 + 0.5f);
+  float acc[8];
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) acc[ch] = 0.f;
+  for (int py = cy - 2; py <= cy + 2; ++py) {
+    if (py < 0 || py >= H) continue;
+    for (int px = cx - 2; px <= cx + 2; ++px) {
+      if (px < 0 || px >= W) continue;
+      const float bx = (2.f * px + 1.f) / W - 1.f, by = (2.f * py + 1.f) / H - 1.f;
+      const float gx = c * bx + s * r * by, gy = (-s / r) * bx + c * by;
+      const Bilin bl = bilin_setup(gx, gy, H, W);
+      const int ox = qx - bl.x0, oy = qy - bl.y0;      // 0 or 1: q is the left / right, upper / lower tap
+      if ((unsigned)ox > 1u || (unsigned)oy > 1u) continue;
+      const float w = (ox ? bl.fx : 1.f - bl.fx) * (oy ? bl.fy : 1.f - bl.fy);
+      const float* g = dy + (long)b * C * H * W + py * W + px;
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch)
+        if (ch < C) acc[ch] += g[(long)ch * H * W] * w;
+    }
   }
+  float* o = dx + (long)b * C * H * W + qy * W + qx;
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch)
+    if (ch < C) o[(long)ch * H * W] += acc[ch];
 }
 
 // ---- ImageLoss: per-sample mean MSE over C channels + w1 * mean |g(sr)-g(hr)| over the first 3 -----------------
@@ -264,6 +282,7 @@ int tatt_rotate_fwd(const float* x, const float* arc, float* y, int B, int C, in
   return TATT_OK;
 }
 int tatt_rotate_bwd(const float* arc, const float* dy, float* dx, int B, int C, int H, int W, hipStream_t st) {
+  TATT_CHECK_ARG(arc && dy && dx && B > 0 && C >= 1 && C <= 8 && H > 0 && W > 0, "tatt_rotate_bwd: need 1 <= C <= 8 (got %d)", C);
   hipLaunchKernelGGL(rotate_bwd_k, dim3(cdiv((long)B * H * W, 256)), dim3(256), 0, st, arc, dy, dx, B, C, H, W);
   TATT_LAUNCH_CHECK("rotate_bwd");
   return TATT_OK;

@@ -578,6 +578,24 @@ def test_tps_rotate_loss_adam():
     dimg = torch.zeros(B, 4, 32, 128, device="cuda")
     L().rotate_bwd(cu(arc), cu(drot), dimg, B, 4, 32, 128)
     close(dimg, img.grad, 5e-5, "rotate bwd")
+    # a gather with a fixed summation order (no atomics): bit-identical from call to call, and it adds onto what dx holds
+    again = torch.zeros(B, 4, 32, 128, device="cuda")
+    L().rotate_bwd(cu(arc), cu(drot), again, B, 4, 32, 128)
+    assert torch.equal(again, dimg)
+    base = cu(rnd(B, 4, 32, 128, seed=9))
+    acc = base.clone()
+    L().rotate_bwd(cu(arc), cu(drot), acc, B, 4, 32, 128)
+    close(acc, base.cpu().double() + img.grad, 5e-5, "rotate bwd (+=)")
+    # angles far beyond the +-10 degrees of the training step, three channels, a small odd-sized image: the candidate window of the
+    # gather must still hold every output pixel that taps an input pixel
+    for (Bq, Cq, Hq, Wq, angles) in ((3, 4, 32, 128, [0.7, -1.3, 3.0]), (2, 3, 7, 10, [0.4, -2.2]), (2, 1, 16, 64, [1.5708, -0.785])):
+        im = torch.rand(Bq, Cq, Hq, Wq).double().requires_grad_(True)
+        ar = torch.tensor(angles)
+        dr = rnd(Bq, Cq, Hq, Wq, seed=4)
+        R.rotate(im, ar.double()).backward(dr.double())
+        got = torch.zeros(Bq, Cq, Hq, Wq, device="cuda")
+        L().rotate_bwd(cu(ar), cu(dr), got, Bq, Cq, Hq, Wq)
+        close(got, im.grad, 5e-5, f"rotate bwd {Hq}x{Wq} {angles}")
     # image loss
     hr = torch.rand(B, 4, 32, 128)
     sr = (hr + 0.1 * rnd(B, 4, 32, 128, seed=3)).clamp(0, 1).double().requires_grad_(True)

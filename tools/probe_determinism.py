@@ -1,5 +1,5 @@
 """Run the B=64 forward+backward pass several times in one process and report every saved tensor / gradient that is not bitwise
-equal between runs (the library's only intended non-deterministic summation is tatt_rotate_bwd, which this pass does not use).
+equal between runs (no kernel of the library sums in a run-dependent order: the last one that did, tatt_rotate_bwd, is a gather now).
 usage: python tools/probe_determinism.py [fp32|f32x3|bf16] [runs]"""
 import os
 import sys
