@@ -199,6 +199,243 @@ __global__ __launch_bounds__(256) void tri_ssim_bwd_k(const float* __restrict__ 
   }
 }
 
+// ---- TRI_SSIM with the Gaussian window applied as two 1-D passes (end of round 3) -------------------------------------------------
+// The 11 x 11 window is the outer product g g^T and the padding is zeros, so blur2d = vertical(horizontal(.)): 22 taps per blurred
+// quantity instead of 121.  The direct kernels above walk the window per pixel with one four-wave workgroup per plane (256 planes at
+// B = 64: one wave per SIMD) and cost 190 us (forward) + 331 us (backward) of the config-3 step, in series between its forward and
+// backward passes.  Here a 1024-thread workgroup owns a plane: the three input planes stay in LDS, the nine products
+// (a, b, c, aa, bb, cc, ab, bc, ca) are blurred along x for a strip of rows (+ 5 halo rows each side; two strips for a 32 x 128
+// plane: 48 KB of inputs + 95 KB of row-blurred maps) and then along y.  The backward pass keeps the four derivative fields of its
+// pixels in registers across the strips, writes them over the dead arena, and blurs them the same way.  Shapes whose strips do not
+// fit (or, in the backward pass, need more than two strips) take the direct kernels.  Sums are reassociated (rounding level).
+constexpr int SEP_THR = 1024, SEP_ARENA = 37888;  // floats of LDS: 151,552 bytes
+constexpr int SEP_NS = 2, SEP_KPS = 2;            // backward: at most two strips of at most SEP_KPS * SEP_THR pixels each
+
+struct SepPlan {
+  int ns, SH, rows;  // strips per plane, output rows per strip, most row-blurred rows a strip needs (plane stride of the maps)
+};
+
+bool sep_plan(int H, int W, SepPlan& pl) {
+  const int HW = H * W;
+  if (HW > MAXHW || getenv("TATT_SSIM_DIRECT")) return false;
+  const int budget = SEP_ARENA - 3 * HW;
+  for (int n = 1; n <= H; ++n) {
+    const int SH = (H + n - 1) / n;
+    int rows = 0;
+    for (int y0 = 0; y0 < H; y0 += SH) {
+      const int lo = y0 - HALF > 0 ? y0 - HALF : 0, hi = y0 + SH + HALF < H ? y0 + SH + HALF : H;
+      if (hi - lo > rows) rows = hi - lo;
+    }
+    if (9 * rows * W <= budget) {
+      pl = SepPlan{(H + SH - 1) / SH, SH, rows};
+      return true;
+    }
+  }
+  return false;
+}
+
+// hq[q][r][x] = sum_dx g[dx] Q_q[lo + r][x + dx - 5] for the nr rows from lo on (zero padding: out-of-range taps get weight 0)
+__device__ __forceinline__ void sep_hpass9(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                           float* __restrict__ hq, int lo, int nr, int rows, int W, const Gauss& G) {
+  const int n = nr * W, ps = rows * W;
+  for (int i = threadIdx.x; i < n; i += SEP_THR) {
+    const int r = i / W, x = i - r * W;
+    const float* ra = a + (lo + r) * W;
+    const float* rb = b + (lo + r) * W;
+    const float* rc = c + (lo + r) * W;
+    float s[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) s[q] = 0.f;
+#pragma unroll
+    for (int dx = 0; dx < WIN; ++dx) {
+      const int xx = x + dx - HALF;
+      const bool ok = (unsigned)xx < (unsigned)W;
+      const int xc = ok ? xx : x;
+      const float w = ok ? G.g[dx] : 0.f;
+      const float va = ra[xc], vb = rb[xc], vc = rc[xc];
+      const float wa = w * va, wb = w * vb, wc = w * vc;
+      s[0] += wa; s[1] += wb; s[2] += wc;
+      s[3] += wa * va; s[4] += wb * vb; s[5] += wc * vc;
+      s[6] += wa * vb; s[7] += wb * vc; s[8] += wc * va;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) hq[q * ps + i] = s[q];
+  }
+}
+
+// the nine blurred quantities of pixel (y, x) from the row-blurred maps of the strip that starts at image row lo
+__device__ __forceinline__ Blur9 sep_vpass9(const float* __restrict__ hq, int lo, int rows, int y, int x, int H, int W, const Gauss& G) {
+  const int ps = rows * W;
+  float s[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) s[q] = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < WIN; ++dy) {
+    const int yy = y + dy - HALF;
+    const bool ok = (unsigned)yy < (unsigned)H;
+    const float w = ok ? G.g[dy] : 0.f;
+    const float* src = hq + ((ok ? yy : y) - lo) * W + x;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) s[q] += w * src[q * ps];
+  }
+  return Blur9{s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]};
+}
+
+__global__ __launch_bounds__(SEP_THR) void tri_ssim_fwd_sep_k(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                              const float* __restrict__ x3, float* __restrict__ partial, int H, int W,
+                                                              int SH, int rows, Gauss G) {
+  __shared__ float arena[SEP_ARENA];
+  __shared__ float red[SEP_THR / 64];
+  const int HW = H * W;
+  const long base = (long)blockIdx.x * HW;
+  float* a = arena;
+  float* b = a + HW;
+  float* c = b + HW;
+  float* hq = c + HW;
+  for (int i = threadIdx.x; i < HW; i += SEP_THR) {
+    a[i] = x1[base + i];
+    b[i] = x2[base + i];
+    c[i] = x3[base + i];
+  }
+  __syncthreads();
+  float s = 0.f;
+  for (int y0 = 0; y0 < H; y0 += SH) {
+    const int lo = max(0, y0 - HALF), hi = min(H, y0 + SH + HALF);
+    sep_hpass9(a, b, c, hq, lo, hi - lo, rows, W, G);
+    __syncthreads();
+    const int n = (min(H, y0 + SH) - y0) * W;
+    for (int i = threadIdx.x; i < n; i += SEP_THR) {
+      const int yr = i / W;
+      s += tri_terms(sep_vpass9(hq, lo, rows, y0 + yr, i - yr * W, H, W, G)).S;
+    }
+    __syncthreads();  // the next strip overwrites the maps
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < SEP_THR / 64; ++w) t += red[w];
+    partial[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(SEP_THR) void tri_ssim_bwd_sep_k(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                              const float* __restrict__ x3, float scale, float* __restrict__ dx1,
+                                                              float* __restrict__ dx2, int accumulate, int H, int W, int SH, int rows,
+                                                              Gauss G) {
+  __shared__ float arena[SEP_ARENA];
+  const int HW = H * W;
+  const long base = (long)blockIdx.x * HW;
+  {
+    float* a = arena;
+    float* b = a + HW;
+    float* c = b + HW;
+    for (int i = threadIdx.x; i < HW; i += SEP_THR) {
+      a[i] = x1[base + i];
+      b[i] = x2[base + i];
+      c[i] = x3[base + i];
+    }
+  }
+  __syncthreads();
+  // phase 1: the four derivative fields of this thread's pixels (dS/dmu1, dS/dmu2, dS/dE12 = dS/dE31 ..., dS/dE11 ...), strip by strip
+  float fv[SEP_NS][SEP_KPS][4];
+#pragma unroll
+  for (int st = 0; st < SEP_NS; ++st) {
+    const int y0 = st * SH;
+    if (y0 < H) {  // block-uniform
+      const float* a = arena;
+      const float* b = a + HW;
+      const float* c = b + HW;
+      float* hq = arena + 3 * HW;
+      const int lo = max(0, y0 - HALF), hi = min(H, y0 + SH + HALF);
+      sep_hpass9(a, b, c, hq, lo, hi - lo, rows, W, G);
+      __syncthreads();
+      const int n = (min(H, y0 + SH) - y0) * W;
+#pragma unroll
+      for (int k = 0; k < SEP_KPS; ++k) {
+        const int i = threadIdx.x + k * SEP_THR;
+        if (i < n) {
+          const int yr = i / W;
+          const Blur9 r = sep_vpass9(hq, lo, rows, y0 + yr, i - yr * W, H, W, G);
+          const Tri t = tri_terms(r);
+          const float icd = 1.f / (t.C * t.D);
+          const float gA = t.Bq * icd, gB = t.A * icd, gC = -t.S / t.C, gD = -t.S / t.D;
+          fv[st][k][0] = (r.m2 + r.m3) * (gA - gB) + 2.f * r.m1 * (gC - gD);
+          fv[st][k][1] = (r.m1 + r.m3) * (gA - gB) + 2.f * r.m2 * (gC - gD);
+          fv[st][k][2] = gB;
+          fv[st][k][3] = gD;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // phase 2: the fields into LDS over the dead arena, blurred along x, then along y and combined with the inputs
+  float* f = arena;            // [4][HW]
+  float* hf = arena + 4 * HW;  // [4][HW]
+#pragma unroll
+  for (int st = 0; st < SEP_NS; ++st) {
+    const int y0 = st * SH;
+    if (y0 < H) {
+      const int n = (min(H, y0 + SH) - y0) * W;
+#pragma unroll
+      for (int k = 0; k < SEP_KPS; ++k) {
+        const int i = threadIdx.x + k * SEP_THR;
+        if (i < n) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) f[q * HW + y0 * W + i] = fv[st][k][q];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < HW; p += SEP_THR) {
+    const int y = p / W, x = p - y * W;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dx = 0; dx < WIN; ++dx) {
+      const int xx = x + dx - HALF;
+      const bool ok = (unsigned)xx < (unsigned)W;
+      const float w = ok ? G.g[dx] : 0.f;
+      const float* src = f + y * W + (ok ? xx : x);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[q] += w * src[q * HW];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hf[q * HW + p] = t[q];
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < HW; p += SEP_THR) {
+    const int y = p / W, x = p - y * W;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < WIN; ++dy) {
+      const int yy = y + dy - HALF;
+      const bool ok = (unsigned)yy < (unsigned)H;
+      const float w = ok ? G.g[dy] : 0.f;
+      const float* src = hf + (ok ? yy : y) * W + x;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[q] += w * src[q * HW];
+    }
+    const float va = x1[base + p], vb = x2[base + p], vc = x3[base + p];
+    const float g1 = scale * (t[0] + 2.f * va * t[3] + (vb + vc) * t[2]);
+    const float g2 = scale * (t[1] + 2.f * vb * t[3] + (va + vc) * t[2]);
+    dx1[base + p] = accumulate ? dx1[base + p] + g1 : g1;
+    dx2[base + p] = accumulate ? dx2[base + p] + g2 : g2;
+  }
+}
+
+// per-plane sums of the tri-SSIM map into partial[planes]
+void launch_tri_fwd(const float* x1, const float* x2, const float* x3, float* partial, int planes, int H, int W, const Gauss& G,
+                    hipStream_t st) {
+  SepPlan pl;
+  if (sep_plan(H, W, pl))
+    hipLaunchKernelGGL(tri_ssim_fwd_sep_k, dim3(planes), dim3(SEP_THR), 0, st, x1, x2, x3, partial, H, W, pl.SH, pl.rows, G);
+  else
+    hipLaunchKernelGGL(tri_ssim_fwd_k, dim3(planes), dim3(256), 0, st, x1, x2, x3, partial, H, W, G);
+}
+
 // ---- scratch of tatt_tri_ssim_fwd_static: the per-plane partial sums that tatt_tri_ssim_fwd takes from its `workspace`
 // argument, held in the code object instead so that the entry point allocates nothing.  64 KB per GPU the library runs on, for
 // the life of the process.  In host code `scratch` is only a stand-in for the symbol: the device address is resolved once per
@@ -243,7 +480,7 @@ int tatt_tri_ssim_fwd(const float* x1, const float* x2, const float* x3, float* 
   TATT_CHECK_ARG(x1 && x2 && x3 && out && workspace && B > 0 && C > 0 && H > 0 && W > 0 && H * W <= MAXHW,
                  "tatt_tri_ssim_fwd: bad arguments (H*W must be <= %d)", MAXHW);
   const Gauss G = make_gauss();
-  hipLaunchKernelGGL(tri_ssim_fwd_k, dim3(B * C), dim3(256), 0, st, x1, x2, x3, workspace, H, W, G);
+  launch_tri_fwd(x1, x2, x3, workspace, B * C, H, W, G, st);
   TATT_LAUNCH_CHECK("tri_ssim_fwd");
   hipLaunchKernelGGL(ssim_final_k, dim3(1), dim3(64), 0, st, workspace, B * C, 1.f / ((float)B * C * H * W), out, 0);
   TATT_LAUNCH_CHECK("tri_ssim_final");
@@ -263,7 +500,7 @@ int tatt_tri_ssim_fwd_static(const float* x1, const float* x2, const float* x3, 
   float* ws = nullptr;
   if (int rc = static_scratch(&ws)) return rc;
   const Gauss G = make_gauss();
-  hipLaunchKernelGGL(tri_ssim_fwd_k, dim3(B * C), dim3(256), 0, st, x1, x2, x3, ws, H, W, G);
+  launch_tri_fwd(x1, x2, x3, ws, B * C, H, W, G, st);
   TATT_LAUNCH_CHECK("tri_ssim_fwd_static");
   hipLaunchKernelGGL(ssim_final_k, dim3(1), dim3(64), 0, st, ws, B * C, 1.f / ((float)B * C * H * W), out, 0);
   TATT_LAUNCH_CHECK("tri_ssim_final_static");
@@ -276,8 +513,13 @@ int tatt_tri_ssim_bwd(const float* x1, const float* x2, const float* x3, float d
   TATT_CHECK_ARG(x1 && x2 && x3 && dx1 && dx2 && B > 0 && C > 0 && H * W <= MAXHW && H > 0 && W > 0,
                  "tatt_tri_ssim_bwd: bad arguments (H*W must be <= %d)", MAXHW);
   const Gauss G = make_gauss();
-  hipLaunchKernelGGL(tri_ssim_bwd_k, dim3(B * C), dim3(256), 0, st, x1, x2, x3, dmean / ((float)B * C * H * W), dx1, dx2, accumulate,
-                     H, W, G);
+  SepPlan pl;
+  if (sep_plan(H, W, pl) && pl.ns <= SEP_NS && pl.SH * W <= SEP_KPS * SEP_THR && 8 * H * W <= SEP_ARENA)
+    hipLaunchKernelGGL(tri_ssim_bwd_sep_k, dim3(B * C), dim3(SEP_THR), 0, st, x1, x2, x3, dmean / ((float)B * C * H * W), dx1, dx2, accumulate,
+                       H, W, pl.SH, pl.rows, G);
+  else
+    hipLaunchKernelGGL(tri_ssim_bwd_k, dim3(B * C), dim3(256), 0, st, x1, x2, x3, dmean / ((float)B * C * H * W), dx1, dx2, accumulate,
+                       H, W, G);
   TATT_LAUNCH_CHECK("tri_ssim_bwd");
   return TATT_OK;
 }

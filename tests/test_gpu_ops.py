@@ -623,9 +623,17 @@ def test_tps_rotate_loss_adam():
     assert float((pd_.cpu() - pr).abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("B,C,H,W", [(3, 4, 32, 128), (2, 4, 16, 64), (1, 3, 9, 13)])
-def test_tri_ssim_ssim_psnr(B, C, H, W):
-    """TRI_SSIM forward/backward (the TSC loss term) and the SSIM / PSNR metrics against the oracle in fp64."""
+@pytest.mark.parametrize("B,C,H,W,direct", [(3, 4, 32, 128, False), (3, 4, 32, 128, True), (2, 4, 16, 64, False), (1, 3, 9, 13, False),
+                                                   (1, 2, 16, 256, False), (1, 1, 4, 1000, False), (2, 1, 64, 64, False)])
+def test_tri_ssim_ssim_psnr(B, C, H, W, direct, monkeypatch):
+    """TRI_SSIM forward/backward (the TSC loss term) and the SSIM / PSNR metrics against the oracle in fp64.
+    The TRI_SSIM launches blur in two 1-D passes with the plane in LDS when the shape fits (32 x 128, 16 x 64, 64 x 64: two strips or
+    one; 16 x 256: sixteen strips forward, the direct window walk backward; 4 x 1000: the direct kernels both ways); `direct` forces the
+    direct kernels for the training shape as well."""
+    if direct:
+        monkeypatch.setenv("TATT_SSIM_DIRECT", "1")
+    else:
+        monkeypatch.delenv("TATT_SSIM_DIRECT", raising=False)
     base = torch.rand(B, C, H, W, generator=torch.Generator().manual_seed(1))
     x1 = (base + 0.05 * rnd(B, C, H, W, seed=2)).clamp(0, 1)
     x2 = (base + 0.05 * rnd(B, C, H, W, seed=3)).clamp(0, 1)
