@@ -9,4 +9,5 @@ db=$(find $out/g -name "*.db" | head -1)
 python3 $GRAFT_REPO_ROOT/tools/graph_gaps.py $db > $out/gaps.txt 2>&1
 python3 $GRAFT_REPO_ROOT/tools/graph_timeline.py $db 40 > $out/graph_timeline.txt 2>&1
 python3 $GRAFT_REPO_ROOT/tools/step_dump.py $db > $out/step_dump.txt 2>&1 || true
+python3 $GRAFT_REPO_ROOT/tools/alone_time.py $db 45 > $out/alone.txt 2>&1 || true
 rm -rf $out/g
