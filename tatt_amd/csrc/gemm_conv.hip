@@ -21,6 +21,9 @@ constexpr int LDA_M = BM;  // row-contiguous A image: [k][m]
 constexpr int LDB_N = BN;  // row-contiguous B image: [k][n]
 constexpr int A_FLOATS = BM * BK;
 constexpr int B_FLOATS = BN * BK;
+// Output tile staged in LDS for the stores: [BM rows][WIDE_LD] floats behind the first WIDE_OFF floats (the epilogues' reduction scratch).
+// WIDE_LD = 72: rows 4 apart (the two halves of a wave) lie 32 banks apart, and rows stay 16-byte aligned.
+constexpr int WIDE_LD = 72, WIDE_OFF = 512, WIDE_FLOATS = WIDE_OFF + BM * WIDE_LD;
 
 enum { OP_STRIDED = 0, OP_ROWCONTIG = 1, OP_IM2COL = 2, OP_CONVW = 3, OP_IM2COL_N = 4, OP_IM2COL_M = 5, OP_CONVW_P = 6 };
 
@@ -58,6 +61,7 @@ struct GemmArgs {
   const float *epi_stat, *epi_gamma, *epi_beta;  // EPI 2: stat [2][epi_C] (mean, invstd)
   int epi_act, epi_C;
   int a16, b16;   // host only: the A / B operand is STORED as bf16 (bf16 precision only; offsets in elements as ever)
+  int wide;       // full output tiles leave through LDS as float4 rows (TATT_WIDE_STORE=0 switches it off)
   int bf16;       // host only, precision of the products: 0 fp32 MFMA, 1 operands rounded to bf16 (TATT_BF16), 2 three bf16 pieces per operand (TATT_F32X3)
   ConvGeom g;     // for OP_IM2COL / OP_CONVW / OP_IM2COL_N
   long w_sn, w_sci, w_stap, w_base;  // OP_CONVW: W[n*w_sn + ci*w_sci + w_base + tap*w_stap]
@@ -248,7 +252,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
   static_assert(!TAP9 || (FAST && AOP == OP_IM2COL && BOP == OP_CONVW_P), "TAP9 is the 3x3 Cin=64 im2col specialisation");
   static_assert(!X3 || (FAST && !BF16 && BOP != OP_CONVW), "X3 exists for the FAST loaders");
   constexpr int H_NPL = X3 ? 3 : 1, H_BBUF = H_NPL * X3_B_PLANE;  // HALO: planes per operand, bytes of one weight-tile buffer
-  __shared__ __attribute__((aligned(16))) float lds[HALO ? (H_NPL * HALO_PLANE + 2 * H_BBUF) / 4 : X3 ? 2 * X3_BUF / 4 : 2 * (A_FLOATS + B_FLOATS)];
+  // (at least WIDE_FLOATS: the epilogue stages the output tile here for full-line stores, see wide_store)
+  constexpr int TILE_LDS = HALO ? (H_NPL * HALO_PLANE + 2 * H_BBUF) / 4 : X3 ? 2 * X3_BUF / 4 : 2 * (A_FLOATS + B_FLOATS);
+  __shared__ __attribute__((aligned(16))) float lds[TILE_LDS > WIDE_FLOATS ? TILE_LDS : WIDE_FLOATS];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -880,6 +886,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
   // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ------------------
   float* Cp = a.C + zb * a.sCb + zs * a.sCz;
   const bool plain = a.splitk == 1;
+  // Full tiles leave through LDS: in the accumulator layout a lane holds sixteen rows of ONE column, i.e. sixteen dword stores per
+  // lane, each wave instruction two 128-byte row segments -- and the CU's store path takes ~20 cycles per wave store instruction
+  // whatever its width (tools/experiments/gru_proj.hip: 6.6 us of a 40 us launch, additive to the matrix time).  Staged as
+  // [row][64 columns] the tile goes out as four float4 stores per thread, each wave instruction four full 256-byte rows:
+  // plain epilogue (EPI 0) 3x3 convolution 47.6 -> 45.4 us, GruBlock projections 42.0 -> 39.2 (K = 128) and 29.4 -> 27.0 us (K = 64).
+  const bool wide_rows = a.wide && a.M - m0 >= BM && a.N - n0 >= BN;  // block-uniform
+  auto wide_store = [&](const float (&v)[16], float* dst, long ldc) {       // dst = &C[m0][first column of this N tile]
+    __syncthreads();  // operand tiles are dead (the reduction scratch in front of the stage may still be read: it is not touched)
+    float* stage = lds + WIDE_OFF;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stage[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * WIDE_LD + wn * 32 + li] = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BM / 32; ++k) {
+      const int row = (tid >> 4) + 32 * k, c4 = tid & 15;
+      *reinterpret_cast<float4*>(dst + (long)row * ldc + c4 * 4) = *reinterpret_cast<const float4*>(stage + row * WIDE_LD + c4 * 4);
+    }
+  };
   if constexpr (EPI != 0) {
     // BatchNorm fused into the epilogue (host guarantees splitk == 1, no accumulate / relu on the first destination).  The
     // workgroup's 128 x 64 tile is reduced over its rows: registers -> the two lane halves -> the four waves along M through LDS.
@@ -971,6 +995,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] += prev[r];
     }
+    // (sixteen dword stores per lane: behind the reductions' barriers the staged form measured no faster -- EPI 1 47.4 -> 47.9 us)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (!ok[r]) continue;
@@ -989,6 +1014,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a) {
       n -= a.nsplit;
       ldc = a.ldc2;
       accum = a.accumulate2;
+    }
+    {
+      float* dst = Cp + (long)m0 * ldc + (n - (wn * 32 + li));
+      if (wide_rows && !(plain && accum) && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {  // block-uniform
+        const bool relu = plain && a.relu;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[r] = acc[r] + bv;
+          if (relu) v[r] = fmaxf(v[r], 0.f);
+        }
+        wide_store(v, dst, ldc);
+        return;
+      }
     }
     float prev[16];
     if (plain && accum) {  // all sixteen reads of the destination in flight together (a read-add-write per row waited on each in turn)
@@ -1026,6 +1065,7 @@ template <int AOP, int BOP, int EPI, bool X3, bool A16 = false>
 __global__ __launch_bounds__(NTHR, 2) void gemm_halo_kernel(GemmArgs a) {
   gemm_body<AOP, BOP, true, !X3, true, EPI, X3, true, A16>(a);
 }
+const int g_wide_store_host = [] { const char* e = getenv("TATT_WIDE_STORE"); return (e && e[0] == '0') ? 0 : 1; }();
 const int g_halo = [] { const char* e = getenv("TATT_CONV_HALO"); return (e && e[0] == '0') ? 0 : 1; }();  // =0: per-tap loads (A/B runs)
 inline bool halo_ok(const GemmArgs& a) {
   return g_halo && a.bf16 != 0 && a.g.W == 64 && a.g.H % 2 == 0 && a.M % BM == 0 && a.M == (a.M / (a.g.H * a.g.W)) * a.g.H * a.g.W &&
@@ -1329,6 +1369,7 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 inline void init_args(GemmArgs& a) {
   memset(&a, 0, sizeof(a));
   a.ksplit = a.nsplit = 0x7fffffff;  // single A source, single destination
+  a.wide = g_wide_store_host;
 }
 const long GIB2 = 1L << 31;
 
