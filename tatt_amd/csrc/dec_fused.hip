@@ -49,6 +49,7 @@ struct DecFwdArgs {
   uint32_t thresh;
   float scale;
   const uint32_t* seed_dev;
+  int wide;                                    // saved tensors leave through wave-private LDS tiles as full lines (TATT_DEC_WIDE=0: 32-byte pieces)
 };
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
@@ -79,6 +80,25 @@ __device__ __forceinline__ void t_store(const T32& x, float* __restrict__ p, int
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<float4*>(p + ob * 32 + g * 8 + hi * 4) =
           make_float4(x.b[ob][g * 4], x.b[ob][g * 4 + 1], x.b[ob][g * 4 + 2], x.b[ob][g * 4 + 3]);
+}
+// The same store through a wave-private LDS tile: in the accumulator layout a lane holds runs of four channels of ITS token, so every
+// wave store instruction above writes 32-byte pieces of 32 different rows (partial lines); the wave's 32 tokens are one contiguous
+// 8 KB block, which leaves as eight instructions of 1 KB each after a transpose.  tile: 32 rows x TW floats (TW = 68: 16-byte rows, row
+// starts four banks apart); blk = the block's first element (token 0 of the wave, channel 0).
+constexpr int TW = 68;
+__device__ __forceinline__ void t_store_wide(const T32& x, float* __restrict__ blk, float* __restrict__ tile, int lane) {
+  const int r = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(tile + r * TW + ob * 32 + g * 8 + hi * 4) =
+          make_float4(x.b[ob][g * 4], x.b[ob][g * 4 + 1], x.b[ob][g * 4 + 2], x.b[ob][g * 4 + 3]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 v = *reinterpret_cast<const float4*>(tile + (i * 4 + (lane >> 4)) * TW + (lane & 15) * 4);
+    *reinterpret_cast<float4*>(blk + (i * 64 + lane) * 4) = v;
+  }
 }
 // acc += M x  (M [64][64] in fragment-major order: slot ((obr*2+obk)*4+g), lane -> M[obr*32 + l%32][obk*32 + g*8 + (l/32)*4 + 0..3])
 __device__ __forceinline__ void mm64(T32& acc, const float4* __restrict__ Wf, int lane, const T32& x) {
@@ -195,6 +215,12 @@ __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
   const int b = (int)(row / (uint32_t)A.Lq), q = (int)(row - (uint32_t)b * (uint32_t)A.Lq), gb = (int)(grow / (uint32_t)A.Lq);
   const long ro = (long)grow * E, rq = (long)row * E;
   const uint32_t sd = A.seed_dev ? A.seed_dev[0] * 0x85EBCA77u : 0u;
+  __shared__ __attribute__((aligned(16))) float wtile[4][32 * TW];
+  const long wro = (long)(blockIdx.x * 128 + wv * 32) * E;   // the wave's 32 tokens: one contiguous block of every [R,64] tensor
+  auto save = [&](const T32& x, float* base) {
+    if (A.wide) t_store_wide(x, base + wro, wtile[wv], lane);
+    else t_store(x, base + ro, hi);
+  };
   T32 tgt, tp;
   t_load(tgt, A.tgt + ro, hi);
 #pragma unroll
@@ -208,10 +234,10 @@ __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
       for (int i = 0; i < 16; ++i) x.b[ob][i] += tgt.b[ob][i];
-    t_store(x, L.sv[0] + ro, hi);
+    save(x, L.sv[0]);
     t_load(y, L.p[0], hi);
     mm64(y, L.Wf + 0 * 1024, lane, x);
-    t_store(y, L.sv[1] + ro, hi);
+    save(y, L.sv[1]);
     // ---- attention: x = context
     t_zero(x);
 #pragma unroll
@@ -232,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
         x.b[h >> 1] = mfma(a.w, p[g * 4 + 3], x.b[h >> 1]);
       }
     }
-    t_store(x, L.sv[2] + ro, hi);
+    save(x, L.sv[2]);
     // ---- out-proj, residual + dropout, LayerNorm2
     t_load(y, L.p[1], hi);
     mm64(y, L.Wf + 1 * 1024, lane, x);
@@ -247,11 +273,11 @@ __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
       for (int i = 0; i < 16; ++i) y.b[ob][i] += tgt.b[ob][i];
-    t_store(y, L.sv[3] + ro, hi);
+    save(y, L.sv[3]);
     float mean, rstd;
     ln_stats(y, mean, rstd);
     ln_apply(tgt, y, mean, rstd, L.p[4], L.p[5], hi);          // tgt <- t2
-    t_store(tgt, L.sv[4] + ro, hi);
+    save(tgt, L.sv[4]);
     // ---- FFN
     t_load(x, L.p[2], hi);
     mm64(x, L.Wf + 2 * 1024, lane, tgt);
@@ -266,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) x.b[ob][i] *= dmask(ss, eidx(row, ob, i, hi), A.thresh, A.scale);
     }
-    t_store(x, L.sv[5] + ro, hi);
+    save(x, L.sv[5]);
     t_load(y, L.p[3], hi);
     mm64(y, L.Wf + 3 * 1024, lane, x);
     if (A.thresh) {
@@ -280,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
       for (int i = 0; i < 16; ++i) y.b[ob][i] += tgt.b[ob][i];
-    t_store(y, L.sv[6] + ro, hi);
+    save(y, L.sv[6]);
     ln_stats(y, mean, rstd);
     ln_apply(tgt, y, mean, rstd, L.p[6], L.p[7], hi);          // tgt <- t3 = the layer's output
     // ---- decoder.norm on the intermediate, mean over the two layers
@@ -291,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void dec_fwd_kernel(DecFwdArgs A) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) tp.b[ob][i] = li == 0 ? 0.5f * y.b[ob][i] : tp.b[ob][i] + 0.5f * y.b[ob][i];
   }
-  t_store(tp, A.tp_map + ro, hi);
+  save(tp, A.tp_map);
 }
 
 // ================================================================================================================================
@@ -713,6 +739,8 @@ __global__ void dec_pack_kv_kernel(const float* __restrict__ Kp, const float* __
 
 }  // namespace
 
+static const int g_dec_wide = [] { const char* e = getenv("TATT_DEC_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
+
 extern "C" {
 
 size_t tatt_dec_packed_w_floats(void) { return (size_t)16 * 4096; }
@@ -776,6 +804,7 @@ int tatt_dec_fwd(const float* tgt, const float* qp, const float* packed_w, const
   a.tgt = tgt; a.qp = qp; a.nw = norm_w; a.nb = norm_b; a.tp_map = tp_map; a.Lq = Lq;
   a.pass_rows = (uint32_t)((long)(B / npass) * Lq);
   a.thresh = thresh; a.scale = scale; a.seed_dev = seed_dev;
+  a.wide = g_dec_wide;
   hipLaunchKernelGGL(dec_fwd_kernel, dim3((unsigned)((long)B * Lq / 128)), dim3(256), 0, st, a);
   TATT_LAUNCH_CHECK("dec_fwd");
   return TATT_OK;
