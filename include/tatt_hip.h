@@ -346,6 +346,8 @@ int tatt_resize_normalize(const unsigned char* data, const long* offsets, const 
 /* ---- ImageLoss = MSE + gradient-prior L1 (loss/image_loss.py:19-32, :40-56), NCHW ------------------------- */
 int tatt_image_loss_fwd(const float* sr, const float* hr, float* per, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);
 int tatt_image_loss_bwd(const float* sr, const float* hr, const float* dper, float uniform, float* dsr, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);
+/* both in one launch (per [B] and dsr = uniform * d per / d sr): the step's form when no per-sample mask weights the gradient */
+int tatt_image_loss_fwd_bwd(const float* sr, const float* hr, float* per, float uniform, float* dsr, int B, int C, int H, int W, float w0, float w1, hipStream_t stream);
 
 /* ---- clip_grad_norm_ + Adam over a flat parameter buffer (interfaces/super_resolution_eng.py:277-279) ------ */
 int tatt_clip_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float max_norm, float* state, float* workspace, hipStream_t stream);

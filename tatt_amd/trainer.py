@@ -22,6 +22,9 @@ import torch.distributed as dist
 
 from .lib import lib
 
+import os
+
+LOSS_ONE_LAUNCH = os.environ.get("TATT_LOSS_ONE_LAUNCH", "1") != "0"   # 0: ImageLoss forward and backward as two launches (A/B runs; same numbers)
 BUCKETS = ["tail", "srbs", "infogen", "head"]
 # Collectives of a data-parallel step: the backward pass announces a finished bucket (Engine.backward(on_stage=...)); at these two
 # announcements ONE all-reduce covers the adjacent buckets named (the flat layout keeps them contiguous).  Few, large collectives: the
@@ -201,14 +204,17 @@ class SRTrainer:
             sr, ctx = self.eng.forward(lr_img, tp, True, 0, tp_ready=tp_ready)
         C, H, W = sr.shape[1:]
         per = torch.empty(B, device=sr.device)
-        L.image_loss_fwd(sr, hr_img, per, B, C, H, W, self.loss_weight[0], self.loss_weight[1])
         dsr_all = torch.empty(2 * B, C, H, W, device=sr.device) if batched else None
         dsr = dsr_all[:B] if batched else torch.empty_like(sr)
         if self.training_stablize:
+            L.image_loss_fwd(sr, hr_img, per, B, C, H, W, self.loss_weight[0], self.loss_weight[1])
             mask = self.loss_stablizing_mask(per)
             per = per * mask
             L.image_loss_bwd(sr, hr_img, mask * (100.0 / B), 0.0, dsr, B, C, H, W, self.loss_weight[0], self.loss_weight[1])
+        elif LOSS_ONE_LAUNCH:                                 # losses (reported only) and gradient in one launch
+            L.image_loss_fwd_bwd(sr, hr_img, per, 100.0 / B, dsr, B, C, H, W, self.loss_weight[0], self.loss_weight[1])
         else:
+            L.image_loss_fwd(sr, hr_img, per, B, C, H, W, self.loss_weight[0], self.loss_weight[1])
             L.image_loss_bwd(sr, hr_img, None, 100.0 / B, dsr, B, C, H, W, self.loss_weight[0], self.loss_weight[1])
         if self.tsc:
             # D(F(Y)), F(D(Y)), D(X): the rotated SR output, the SR of the rotated input, the rotated HR image

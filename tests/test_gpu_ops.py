@@ -607,6 +607,10 @@ def test_tps_rotate_loss_adam():
     dsr = torch.empty(B, 4, 32, 128, device="cuda")
     L().image_loss_bwd(cu(sr.detach().float()), cu(hr), None, 100.0 / B, dsr, B, 4, 32, 128, 1.0, 1e-4)
     close(dsr, sr.grad, 5e-5, "image loss bwd")
+    # both in one launch (the training step's form): the same numbers, bit for bit
+    pd2, dsr2 = torch.full((B,), float("nan"), device="cuda"), torch.full((B, 4, 32, 128), float("nan"), device="cuda")
+    L().image_loss_fwd_bwd(cu(sr.detach().float()), cu(hr), pd2, 100.0 / B, dsr2, B, 4, 32, 128, 1.0, 1e-4)
+    assert torch.equal(pd2, pd) and torch.equal(dsr2, dsr)
     # clip + adam (two steps)
     n = 100000
     p0, g1, g2 = rnd(n), rnd(n, seed=1) * 0.01, rnd(n, seed=2) * 0.0001
