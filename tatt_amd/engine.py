@@ -320,13 +320,15 @@ class Engine:
         z = self.new(wsz)                                      # 9x9, Cout = 4 (direct kernel): the packed weights; else planar Z [(tap,co)][pixel]
         self.L.conv_skinny_fwd(x, W, b, out, B, H, Wd, Cin, Cout, k, k, Cin, Cout, *wstr, acc | (self.px if fp32 else self.pf), z)
 
-    def _prepack(self, use_stn):
+    def _prepack(self, use_stn, training=False):
         """Pack every convolution weight of the network for this forward call with ONE launch (tatt_conv_pack_w_group)."""
         m, P = self.m, self.P
         names = ["block1.0.weight"]
         for i in range(m.srb_nums):
             names += [f"block{i + 2}.conv1.weight", f"block{i + 2}.conv2.weight"]
         names += [f"block{m.srb_nums + 2}.0.weight", f"block{m.srb_nums + 3}.0.conv.weight"]
+        if training:   # the 9x9 output convolution's input gradient runs on the tiled kernel: its pack would otherwise be a launch of
+            names.append(f"block{m.srb_nums + 3}.1.weight")   # its own at the head of the backward pass, alone on the GPU
         if use_stn:
             names += [f"stn_head.stn_convnet.{idx}.0.weight" for idx, *_ in STN_STAGES]
         Ws = [P[n] for n in names if P[n].data_ptr() not in self.wpack]
@@ -942,7 +944,7 @@ class Engine:
 
         # per-step weight packs of the main strand (conv weights in MFMA order, 1x1 conv folded into the GRU projections): issued
         # after the two forks, which need neither
-        self._prepack(use_stn)
+        self._prepack(use_stn, training)
         self._gru_fold()
 
         # ---- STN head + TPS rectification (model/tsrn.py:655-657), per pass --------------------------------
