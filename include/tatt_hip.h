@@ -142,6 +142,12 @@ int tatt_bn_bwd(const float* x, long ldx, const float* dy, long lddy, const floa
 int tatt_conv_fwd_bn(const float* X, const float* Wt, const float* bias, float* Y, int B, int H, int W, int Cin, int Cout, int KH, int KW, long ldx, long ldy, long w_sn, long w_sci, long w_base, long w_stap, int flags, int epi, const float* bn_x, long bn_ldx, const float* bn_stat, const float* bn_gamma, const float* bn_beta, int bn_act, float* partial, hipStream_t stream);
 int tatt_gemm_cat_bnbwd(const float* A, const float* A2, int ksplit, const float* B, float* C, float* C2, int nsplit, const float* bias, int M, int N, int K, long sam, long sbn, long sbk, long ldc, long ldc2, int accumulate, int accumulate2, int flags, const float* bn_x, long bn_ldx, const float* bn_stat, const float* bn_gamma, const float* bn_beta, int bn_act, int bn_C, float* partial, hipStream_t stream);
 int tatt_bn_stats_from_partial(const float* partial, int nblk, int rows_per_blk, int R, int C, float eps, float momentum, float* stat, float* run_mean, float* run_var, hipStream_t stream);
+/* The batched TSC step pushes both SR passes through one convolution launch but keeps BatchNorm per pass: the per-pass
+ * finals and applies as ONE launch each -- ng groups of R rows, partial [ng][nblk][2][C], stat [ng][2][C], running statistics updated
+ * group after group; apply: row r uses stat[r / Rg] (Rg a multiple of the apply kernel's rows per block: 8192 / C for C <= 1024). */
+int tatt_bn_stats_from_partial_groups(const float* partial, int nblk, int rows_per_blk, int R, int C, int ng, float eps, float momentum, float* stat, float* run_mean, float* run_var, hipStream_t stream);
+int tatt_bn_apply_groups(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr, float* y, long ldy, int R, int C, int act, int Rg, hipStream_t stream);
+int tatt_bn_apply_bf16_groups(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr, uint16_t* y, long ldy, int R, int C, int act, int Rg, hipStream_t stream);
 int tatt_bn_bwd_from_partial(const float* x, long ldx, const float* g, long ldg, const float* stat, const float* gamma, const float* beta, const float* partial, int nblk, float* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int train, int accumulate_params, int accumulate_dx, float* sums, hipStream_t stream);
 /* the same with dx stored as bf16 (no accumulation onto dx): the gradient that only the convolution's dgrad / wgrad launches read */
 int tatt_bn_bwd_from_partial_bf16(const float* x, long ldx, const float* g, long ldg, const float* stat, const float* gamma, const float* beta, const float* partial, int nblk, uint16_t* dx, long lddx, float* dgamma, float* dbeta, int R, int C, int train, int accumulate_params, float* sums, hipStream_t stream);

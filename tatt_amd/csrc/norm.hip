@@ -5,6 +5,10 @@ namespace {
 
 constexpr int BN_MAXBLK = 256;
 constexpr int BN_RPT = 8;  // rows per thread of the apply kernels
+inline int bn_rows_per_block(int C) {
+  const int c4 = C / 4, CT = c4 < 256 ? c4 : 256, RL = 256 / CT;
+  return RL * BN_RPT;
+}
 inline int bn_apply_grid(int R, int C) {
   const int c4 = C / 4, CT = c4 < 256 ? c4 : 256, RL = 256 / CT;
   return cdiv(R, RL * BN_RPT);
@@ -137,9 +141,64 @@ __global__ __launch_bounds__(256) void bn_stats_final(const float* __restrict__ 
   stat[c] = mean;
   stat[C + c] = rsqrtf(var + eps);
   if (run_mean) {
-    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+    // (explicit fma: the grouped form below must round like this one whatever the compiler contracts)
+    run_mean[c] = fmaf(momentum, mean, (1.f - momentum) * run_mean[c]);
     float unb = n > 1.f ? m2 / (n - 1.f) : var;
-    run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+    run_var[c] = fmaf(momentum, unb, (1.f - momentum) * run_var[c]);
+  }
+}
+
+// The same merge for ng statistics groups in ONE launch (the two SR passes of a batched TSC step: one convolution launch, BatchNorm
+// per pass): partial [ng][nblk][2][C], stat [ng][2][C]; the running statistics take the groups' updates one after the other, in
+// group order, exactly as ng launches of bn_stats_final would leave them.
+__global__ __launch_bounds__(256) void bn_stats_final_groups(const float* __restrict__ partial, int nblk, int ng, int R, int C, int rows_per_blk,
+                                                              float eps, float momentum, float* __restrict__ stat, float* __restrict__ run_mean,
+                                                              float* __restrict__ run_var, int cpb) {
+  __shared__ float sn[256], sm[256], s2[256];
+  const int RLN = blockDim.x / cpb;
+  const int cl = threadIdx.x % cpb, rl = threadIdx.x / cpb;
+  const int c = blockIdx.x * cpb + cl;
+  const bool fin = rl == 0 && c < C;
+  float rmean = 0.f, rvar = 0.f;
+  if (fin && run_mean) {
+    rmean = run_mean[c];
+    rvar = run_var[c];
+  }
+  for (int g = 0; g < ng; ++g) {
+    const float* __restrict__ pg = partial + (long)g * nblk * 2 * C;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (c < C)
+      for (int b = rl; b < nblk; b += RLN) {
+        const float nb = (float)(min(R, (b + 1) * rows_per_blk) - b * rows_per_blk);
+        chan_merge(n, mean, m2, nb, pg[((long)b * 2 + 0) * C + c], pg[((long)b * 2 + 1) * C + c]);
+      }
+    sn[threadIdx.x] = n; sm[threadIdx.x] = mean; s2[threadIdx.x] = m2;
+    __syncthreads();
+    if (RLN > 8) {
+      if (rl < 8) {
+        n = 0.f; mean = 0.f; m2 = 0.f;
+        for (int j = rl; j < RLN; j += 8) chan_merge(n, mean, m2, sn[j * cpb + cl], sm[j * cpb + cl], s2[j * cpb + cl]);
+      }
+      __syncthreads();
+      if (rl < 8) { sn[threadIdx.x] = n; sm[threadIdx.x] = mean; s2[threadIdx.x] = m2; }
+      __syncthreads();
+    }
+    if (fin) {
+      n = 0.f; mean = 0.f; m2 = 0.f;
+      const int last = RLN > 8 ? 8 : RLN;
+      for (int j = 0; j < last; ++j) chan_merge(n, mean, m2, sn[j * cpb + cl], sm[j * cpb + cl], s2[j * cpb + cl]);
+      const float var = m2 / n;
+      stat[((long)g * 2 + 0) * C + c] = mean;
+      stat[((long)g * 2 + 1) * C + c] = rsqrtf(var + eps);
+      const float unb = n > 1.f ? m2 / (n - 1.f) : var;
+      rmean = fmaf(momentum, mean, (1.f - momentum) * rmean);
+      rvar = fmaf(momentum, unb, (1.f - momentum) * rvar);
+    }
+    __syncthreads();  // the scratch is reused by the next group
+  }
+  if (fin && run_mean) {
+    run_mean[c] = rmean;
+    run_var[c] = rvar;
   }
 }
 
@@ -159,13 +218,15 @@ __global__ void bn_stat_from_running(const float* __restrict__ rm, const float* 
 template <int ACT, bool OUT16 = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ stat,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ res, long ldr, float* __restrict__ y, long ldy, int R, int C) {
+                                                       const float* __restrict__ res, long ldr, float* __restrict__ y, long ldy, int R, int C, int Rg) {
+  // Rg: rows per statistics group (R for one set; a multiple of the block's rows): stat [R / Rg][2][C]
   // thread = (float4 channel group, row lane); the channel group's scale/shift is folded once and kept in registers while the
   // thread walks BN_RPT rows (one thread per float4 re-read 16 parameters for every 16 bytes of payload)
   const int c4 = C >> 2, CT = c4 < 256 ? c4 : 256, RL = 256 / CT;
   const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
   if (rl >= RL) return;
   const int rbase = blockIdx.x * (RL * BN_RPT) + rl;
+  stat += (long)((blockIdx.x * (RL * BN_RPT)) / Rg) * 2 * C;
   for (int cg = cl; cg < c4; cg += CT) {
     const int c = cg * 4;
     float mu[4], sc[4], ga[4], sh[4];
@@ -751,11 +812,14 @@ int tatt_bn_stat_from_running(const float* rm, const float* rv, int C, float eps
   return TATT_OK;
 }
 
-int tatt_bn_apply(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr,
-                  float* y, long ldy, int R, int C, int act, hipStream_t st) {
+// rows r of group r / Rg are normalised with stat[r / Rg] ([groups][2][C]); Rg = R: one set of statistics
+int tatt_bn_apply_groups(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr,
+                         float* y, long ldy, int R, int C, int act, int Rg, hipStream_t st) {
   TATT_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "tatt_bn_apply: C/ld must be multiples of 4");
   TATT_CHECK_ARG(act >= 0 && act <= 2 && R > 0, "tatt_bn_apply: act must be 0 (none), 1 (relu) or 2 (mish)");
-#define BN_APPLY(A) hipLaunchKernelGGL(bn_apply_kernel<A>, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, stat, gamma, beta, res, ldr, y, ldy, R, C)
+  TATT_CHECK_ARG(Rg > 0 && (Rg == R || (R % Rg == 0 && Rg % bn_rows_per_block(C) == 0)),
+                 "tatt_bn_apply_groups: rows per group (%d) must divide R and be a multiple of %d", Rg, bn_rows_per_block(C));
+#define BN_APPLY(A) hipLaunchKernelGGL(bn_apply_kernel<A>, dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, stat, gamma, beta, res, ldr, y, ldy, R, C, Rg)
   if (act == 0) BN_APPLY(0);
   else if (act == 1) BN_APPLY(1);
   else BN_APPLY(2);
@@ -763,20 +827,30 @@ int tatt_bn_apply(const float* x, long ldx, const float* stat, const float* gamm
   TATT_LAUNCH_CHECK("bn_apply");
   return TATT_OK;
 }
+int tatt_bn_apply(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr,
+                  float* y, long ldy, int R, int C, int act, hipStream_t st) {
+  return tatt_bn_apply_groups(x, ldx, stat, gamma, beta, res, ldr, y, ldy, R, C, act, R, st);
+}
 
 // tatt_bn_apply with y stored as bf16 (round to nearest even; ldy in elements, y 8-byte aligned)
-int tatt_bn_apply_bf16(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr,
-                       uint16_t* y, long ldy, int R, int C, int act, hipStream_t st) {
+int tatt_bn_apply_bf16_groups(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr,
+                              uint16_t* y, long ldy, int R, int C, int act, int Rg, hipStream_t st) {
   TATT_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)y) & 7) == 0, "tatt_bn_apply_bf16: C/ld must be multiples of 4, y 8-byte aligned");
   TATT_CHECK_ARG(act >= 0 && act <= 2 && R > 0, "tatt_bn_apply_bf16: act must be 0 (none), 1 (relu) or 2 (mish)");
+  TATT_CHECK_ARG(Rg > 0 && (Rg == R || (R % Rg == 0 && Rg % bn_rows_per_block(C) == 0)),
+                 "tatt_bn_apply_bf16_groups: rows per group (%d) must divide R and be a multiple of %d", Rg, bn_rows_per_block(C));
   float* yf = reinterpret_cast<float*>(y);
-#define BN_APPLY(A) hipLaunchKernelGGL((bn_apply_kernel<A, true>), dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, stat, gamma, beta, res, ldr, yf, ldy, R, C)
+#define BN_APPLY(A) hipLaunchKernelGGL((bn_apply_kernel<A, true>), dim3(bn_apply_grid(R, C)), dim3(256), 0, st, x, ldx, stat, gamma, beta, res, ldr, yf, ldy, R, C, Rg)
   if (act == 0) BN_APPLY(0);
   else if (act == 1) BN_APPLY(1);
   else BN_APPLY(2);
 #undef BN_APPLY
   TATT_LAUNCH_CHECK("bn_apply<bf16 out>");
   return TATT_OK;
+}
+int tatt_bn_apply_bf16(const float* x, long ldx, const float* stat, const float* gamma, const float* beta, const float* res, long ldr,
+                       uint16_t* y, long ldy, int R, int C, int act, hipStream_t st) {
+  return tatt_bn_apply_bf16_groups(x, ldx, stat, gamma, beta, res, ldr, y, ldy, R, C, act, R, st);
 }
 
 // Backward through y = act(bn(x)).  workspace: tatt_bn_workspace(C) floats.
@@ -809,6 +883,16 @@ int tatt_bn_stats_from_partial(const float* partial, int nblk, int rows_per_blk,
   hipLaunchKernelGGL(bn_stats_final, dim3(cdiv(C, nblk > 128 ? 4 : 16)), dim3(256), 0, st, partial, nblk, R, C, rows_per_blk, eps, momentum, stat, run_mean,
                      run_var, nblk > 128 ? 4 : 16);
   TATT_LAUNCH_CHECK("bn_stats_final");
+  return TATT_OK;
+}
+// ng groups of R rows each in one launch: partial [ng][nblk][2][C], stat [ng][2][C]; running statistics updated group after group
+int tatt_bn_stats_from_partial_groups(const float* partial, int nblk, int rows_per_blk, int R, int C, int ng, float eps, float momentum,
+                                      float* stat, float* run_mean, float* run_var, hipStream_t st) {
+  TATT_CHECK_ARG(partial && stat && nblk > 0 && rows_per_blk > 0 && (long)nblk * rows_per_blk >= R && (long)(nblk - 1) * rows_per_blk < R && C > 0 &&
+                     ng >= 1, "tatt_bn_stats_from_partial_groups: bad arguments");
+  hipLaunchKernelGGL(bn_stats_final_groups, dim3(cdiv(C, nblk > 128 ? 4 : 16)), dim3(256), 0, st, partial, nblk, ng, R, C, rows_per_blk, eps, momentum,
+                     stat, run_mean, run_var, nblk > 128 ? 4 : 16);
+  TATT_LAUNCH_CHECK("bn_stats_final_groups");
   return TATT_OK;
 }
 

@@ -22,6 +22,7 @@ DROP_SITES = {
 }
 STN_STAGES = [(0, 4, 32, (2, 2)), (2, 32, 64, (2, 2)), (4, 64, 128, (2, 2)), (6, 128, 256, (2, 2)),
               (8, 256, 256, (1, 2)), (10, 256, 256, None)]
+BN_GROUPED = os.environ.get("TATT_BN_GROUPED", "1") != "0"   # 0: the two passes of a batched TSC step get a BatchNorm final + apply launch each (A/B)
 RPE_CHAIN = os.environ.get("TATT_RPE_CHAIN", "1") != "0"   # 0: one launch per step of the RPE recurrence (A/B runs)
 DEC_FUSED = os.environ.get("TATT_DEC_FUSED", "1") != "0"   # 0: the decoder as one launch per projection / attention / LayerNorm (A/B runs)
 WS_FLOATS = 48 * 1024 * 1024
@@ -449,6 +450,13 @@ class Engine:
         stat = self.new(ng, 2, Cout)
         y = self.new16(R, Cout) if (out16 and self.store16) else self.new(R, Cout)
         apply = self.L.bn_apply_bf16 if y.dtype == torch.bfloat16 else self.L.bn_apply
+        if ng > 1 and BN_GROUPED and Rg % (8192 // Cout if Cout <= 1024 else 8) == 0:
+            # both passes' finals in one launch (running statistics updated pass after pass), both applies in one launch
+            self.L.bn_stats_from_partial_groups(part, nblk, 128, Rg, Cout, ng, 1e-5, 0.1, stat, P[pre_bn + "running_mean"], P[pre_bn + "running_var"])
+            self._nbt += [P[pre_bn + "num_batches_tracked"]] * ng
+            (self.L.bn_apply_bf16_groups if y.dtype == torch.bfloat16 else self.L.bn_apply_groups)(
+                c, Cout, stat, P[pre_bn + "weight"], P[pre_bn + "bias"], res, Cout, y, Cout, R, Cout, act, Rg)
+            return c, y, stat
         for g in range(ng):
             self.L.bn_stats_from_partial(part[g * nblk * 2 * Cout:], nblk, 128, Rg, Cout, 1e-5, 0.1, stat[g], P[pre_bn + "running_mean"],
                                          P[pre_bn + "running_var"])

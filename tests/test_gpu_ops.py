@@ -748,6 +748,38 @@ def test_conv_fwd_bn_statistics_in_the_epilogue(B, H, W, Cin, Cout):
     close(rv, 0.9 * rv0.cpu().double() + 0.1 * y.var((0, 2, 3), unbiased=True), 2e-5, "running_var")
 
 
+@pytest.mark.parametrize("C,out16", [(64, False), (64, True), (256, False)])
+def test_grouped_batchnorm_final_and_apply_equal_one_launch_per_group(C, out16):
+    """The batched TSC step's BatchNorm: tatt_bn_stats_from_partial_groups / tatt_bn_apply(_bf16)_groups over two passes in ONE launch each
+    against the per-pass launches, bit for bit -- statistics, running statistics (updated pass after pass) and the normalised rows."""
+    Rg, ng, act = 2048, 2, 2
+    R_, nblk = Rg * ng, Rg // 128
+    x = cu(rnd(R_, C) * 1.3 + 0.2)
+    x[Rg:] *= 0.5                                                            # the passes have different statistics
+    part = torch.empty(ng, nblk, 2, C, device="cuda")
+    xb = x.view(ng, nblk, 128, C)
+    part[:, :, 0] = xb.mean(2)
+    part[:, :, 1] = ((xb - xb.mean(2, keepdim=True)) ** 2).sum(2)
+    ga, be, res = cu(1 + 0.1 * rnd(C, seed=1)), cu(0.1 * rnd(C, seed=2)), cu(rnd(R_, C, seed=3))
+    rm0, rv0 = cu(rnd(C, seed=4)), cu(rnd(C, seed=5).abs() + 0.5)
+    ydt = torch.bfloat16 if out16 else torch.float32
+    # per pass
+    s1, rm1, rv1 = torch.empty(ng, 2, C, device="cuda"), rm0.clone(), rv0.clone()
+    y1 = torch.empty(R_, C, device="cuda", dtype=ydt)
+    for g in range(ng):
+        L().bn_stats_from_partial(part[g], nblk, 128, Rg, C, 1e-5, 0.1, s1[g], rm1, rv1)
+        (L().bn_apply_bf16 if out16 else L().bn_apply)(x[g * Rg:], C, s1[g], ga, be, res[g * Rg:], C, y1[g * Rg:], C, Rg, C, act)
+    # grouped
+    s2, rm2, rv2 = torch.empty(ng, 2, C, device="cuda"), rm0.clone(), rv0.clone()
+    y2 = torch.empty(R_, C, device="cuda", dtype=ydt)
+    L().bn_stats_from_partial_groups(part, nblk, 128, Rg, C, ng, 1e-5, 0.1, s2, rm2, rv2)
+    (L().bn_apply_bf16_groups if out16 else L().bn_apply_groups)(x, C, s2, ga, be, res, C, y2, C, R_, C, act, Rg)
+    assert torch.equal(s1, s2) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2) and torch.equal(y1, y2)
+    assert not torch.equal(s1[0], s1[1])
+    with pytest.raises(RuntimeError):
+        L().bn_apply_groups(x, C, s2, ga, be, res, C, y2.float(), C, R_, C, act, Rg - 1)        # rows per group must fit the blocks
+
+
 @pytest.mark.parametrize("act", [0, 1, 2])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 16, 64, 64, 64), (1, 7, 19, 64, 256)])
 def test_conv_dgrad_with_batchnorm_backward_in_the_epilogue(B, H, W, Cin, Cout, act):
